@@ -1,0 +1,87 @@
+"""ctypes binding of libpp_hip.so (include/pp_hip.h).  Fails loudly when the HIP
+extension is missing: there is no CPU fallback in the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpp_hip.so")
+PP_MAX_CLASSES = 8
+
+c_f = ctypes.c_float
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_p = ctypes.c_void_p
+
+
+class PPConfig(ctypes.Structure):
+    _fields_ = [
+        ("voxel_size", c_f * 3),
+        ("offset", c_f * 3),
+        ("grid_size", c_i32 * 3),
+        ("max_voxels", c_i32),
+        ("max_num_points", c_i32),
+        ("num_point_features", c_i32),
+        ("max_points", c_i32),
+        ("num_anchor_per_loc", c_i32),
+        ("num_classes", c_i32),
+        ("class_begin", c_i32 * PP_MAX_CLASSES),
+        ("class_end", c_i32 * PP_MAX_CLASSES),
+        ("center_limit", ctypes.c_double * 6),
+        ("norm_kind", c_i32),
+        ("nms_pre_max", c_i32),
+        ("nms_post_max", c_i32),
+        ("nms_iou_threshold", c_f),
+        ("score_threshold", c_f),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/pp_hip.h declares
+PROTOTYPES = {
+    "pp_create": (c_p, [ctypes.c_int, ctypes.POINTER(PPConfig)]),
+    "pp_destroy": (None, [c_p]),
+    "pp_last_error": (ctypes.c_char_p, [c_p]),
+    "pp_load_weights": (ctypes.c_int, [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), ctypes.c_int]),
+    "pp_commit_weights": (ctypes.c_int, [c_p]),
+    "pp_set_anchors": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
+    "pp_voxelize": (ctypes.c_int, [c_p, c_p, ctypes.c_int, ctypes.c_int, c_p, c_p, c_p, c_p, c_p]),
+    "pp_anchor_mask": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p]),
+    "pp_pfn": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "pp_scatter": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "pp_backbone": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
+    "pp_head": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "pp_postprocess": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_infer_frame": (ctypes.c_int, [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_box_decode": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p]),
+    "pp_corners2d": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "pp_standup2d": (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
+    "pp_nms": (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_int, c_f, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_rotated_iou": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, c_p]),
+    "pp_profile_begin": (ctypes.c_int, [c_p]),
+    "pp_profile_end": (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
+    "pp_version": (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpp_hip.so; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C 3d_object_detection_amd/csrc)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, ctx=None, what=""):
+    if rc != 0:
+        msg = load().pp_last_error(ctx)
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,869 @@
+// 2D backbone (RPN) + shared head as fp32 MFMA implicit GEMMs for gfx950.
+// Reference: networks/pointpillars8_shared.py:114-181 (RPN), :299-343 (SharedHead),
+// :418-431 (Resnet2); BatchNorm variant networks/pointpillars8_export.py:54-119.
+//
+// One kernel template covers conv3x3 (stride 1/2), ConvTranspose(k == stride) and the 1x1 head:
+//
+//   D[cout, pixel] = sum_k  Wt[cout, k] * X[k, pixel]        k = (tap, cin)
+//
+// * MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain).  M = 16 output channels,
+//   N = 16 output pixels, K = 4 input channels of one filter tap.  Pixels sit on the LANE axis of
+//   the C/D layout (col = lane&15), channels in the 4 accumulator registers, so one store
+//   instruction writes 16 consecutive pixels of a channel (NCHW, coalesced) and the per-channel
+//   InstanceNorm statistics reduce with 4 xor-shuffles.
+// * Tensors stay NCHW (the reference layout): for a fixed (cin, tap) the 16 pixels of an N-tile are
+//   contiguous in the LDS patch, so the B-operand read is one conflict-free ds_read_b32.
+// * No im2col: each workgroup stages a [KC][IH][IW] input patch with halo ONCE per channel chunk
+//   and walks the 9 taps as shifted windows of it.  Zero padding, the producer's normalisation
+//   (InstanceNorm / folded BatchNorm as x*scale+shift) and ReLU are applied while staging, so
+//   normalised activations are never materialised in HBM.
+// * InstanceNorm2d(eps=1e-3, affine=False) needs full-plane statistics of every conv output: the
+//   epilogue reduces sum / sum-of-squares per channel (fp32 over <= 64 pixels, then fp64) and adds
+//   them to 8 replicated fp64 accumulators; the CONSUMER kernel turns them into (scale, shift) in
+//   its prologue.  No separate statistics pass, no finalize launch.
+// * ConvTranspose(k = s, stride = s) is a 1x1 conv onto Cout*s*s virtual channels whose epilogue
+//   pixel-shuffles (float2 / float4 stores); the three upsampled maps land in one [320,H,W]
+//   buffer, so the concat is free and the head normalises + ReLUs them in its prologue.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "pp_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NREP = 8; // replicated statistics accumulators (spreads atomic contention)
+
+enum { EPI_PLAIN = 0, EPI_UP2 = 1, EPI_UP4 = 2, EPI_HEAD = 3 };
+enum { PRE_RAW = 0, PRE_STATS = 1, PRE_AFFINE = 2 };
+
+struct ConvP {
+    const float* in;
+    const float* w;   // packed [cout_block][chunk][tap][kc][BM]
+    float* out;
+    const float* res; // residual, same layout as out (nullable)
+    int Cin, Hin, Win;
+    int Cout;         // rows of the GEMM (virtual channels for deconv, 96 for the head)
+    int Hout, Wout;   // pixel grid of the GEMM
+    int pre;
+    const double* pre_acc; // [NREP][Cin][2]
+    const float* pre_scale;
+    const float* pre_shift;
+    double pre_inv_n;
+    float eps;
+    double* stat_acc; // [NREP][Cstat][2] (nullable)
+    int stat_C;       // channels in stat_acc
+    // head
+    const float* bias;
+    float* out_box;
+    float* out_dir;
+    int n_cls, n_box; // 9, 63 (dir = rest up to n_rows)
+    int n_rows;       // 90
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
+struct ConvCfg {
+    static constexpr int TH = 16 / TW;
+    static constexpr int TILES = WN * NT;
+    static constexpr int BTY = TILES / BTX;
+    static constexpr int PW = BTX * TW, PH = BTY * TH;
+    static constexpr int IW = (PW - 1) * STRIDE + KS, IH = (PH - 1) * STRIDE + KS;
+    static constexpr int iwp()
+    {
+        if (TW == 16) return IW;
+        int v = IW;
+        while ((STRIDE * v) % 32 != TW) ++v; // rows of an N-tile land on disjoint bank groups
+        return v;
+    }
+    static constexpr int IWP = iwp();
+    static constexpr int cs()
+    {
+        int v = IH * IWP;
+        while (v % 32 != 16) ++v; // channel c+1 is 16 banks away from channel c
+        return v;
+    }
+    static constexpr int CS = cs();
+    static constexpr int BM = WM * MT * 16;
+    static constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int LDS_IN = KC * CS;
+    static constexpr int LDS_W = KS * KS * KC * BMP;
+    static constexpr int LDS_FLOATS = LDS_IN + LDS_W + 2 * 320 + 2 * WN * BM;
+    static_assert(TILES % BTX == 0, "tiles must form a rectangle");
+    static_assert(KC % 4 == 0, "KC multiple of the MFMA K");
+};
+
+template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
+__global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
+{
+    using C = ConvCfg<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* il = smem;                // [KC][CS]
+    float* wl = il + C::LDS_IN;      // [KS*KS][KC][BMP]
+    float* scl = wl + C::LDS_W;      // [320] scale
+    float* shl = scl + 320;          // [320] shift
+    float* red = shl + 320;          // [WN][BM][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m = lane & 15, kq = lane >> 4;
+
+    const int nbx = (p.Wout + C::PW - 1) / C::PW;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int co0 = blockIdx.y * C::BM;
+    const int ox0 = bx * C::PW, oy0 = by * C::PH;
+    const int ix0 = ox0 * STRIDE - KS / 2, iy0 = oy0 * STRIDE - KS / 2;
+
+    // ---- prologue: per-input-channel (scale, shift) of the producer's normalisation ----
+    if (p.pre == PRE_STATS) {
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                s += p.pre_acc[((size_t)r * p.Cin + c) * 2];
+                q += p.pre_acc[((size_t)r * p.Cin + c) * 2 + 1];
+            }
+            double mean = s * p.pre_inv_n;
+            double var = q * p.pre_inv_n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            double rstd = 1.0 / sqrt(var + (double)p.eps);
+            scl[c] = (float)rstd;
+            shl[c] = (float)(-mean * rstd);
+        }
+    } else if (p.pre == PRE_AFFINE) {
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            scl[c] = p.pre_scale[c];
+            shl[c] = p.pre_shift[c];
+        }
+    }
+
+    // lane's pixel base inside the LDS patch for each of its N-tiles
+    int toff[NT];
+    int opx[NT], opy[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int t = wn * NT + nt;
+        const int tx = t % BTX, ty = t / BTX;
+        const int px = tx * TW + (m % TW), py = ty * C::TH + (m / TW);
+        opx[nt] = ox0 + px;
+        opy[nt] = oy0 + py;
+        toff[nt] = (py * STRIDE) * C::IWP + px * STRIDE + kq * C::CS;
+    }
+    const int aoff = kq * C::BMP + wm * MT * 16 + m;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const size_t in_plane = (size_t)p.Hin * p.Win;
+    const int nchunk = p.Cin / KC;
+    const float* wsrc = p.w + (size_t)blockIdx.y * nchunk * (KS * KS * KC * C::BM);
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads(); // previous chunk fully consumed (and scl/shl visible on the first pass)
+        // ---- stage the input patch: zero padding + normalise + ReLU on the fly ----
+        const int c0 = ch * KC;
+        for (int idx = tid; idx < KC * C::IH * C::IW; idx += C::THREADS) {
+            const int c = idx / (C::IH * C::IW);
+            const int r = idx - c * (C::IH * C::IW);
+            const int iy = r / C::IW, ix = r - iy * C::IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            float v = 0.f;
+            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) {
+                v = p.in[(size_t)(c0 + c) * in_plane + (size_t)gy * p.Win + gx];
+                if (p.pre != PRE_RAW) v = fmaxf(fmaf(v, scl[c0 + c], shl[c0 + c]), 0.f);
+            }
+            il[c * C::CS + iy * C::IWP + ix] = v;
+        }
+        // ---- stage the weight slab [tap][kc][BM] -> padded rows ----
+        {
+            const float4* g = reinterpret_cast<const float4*>(wsrc + (size_t)ch * (KS * KS * KC * C::BM));
+            constexpr int N4 = KS * KS * KC * C::BM / 4;
+            for (int e = tid; e < N4; e += C::THREADS) {
+                const int row = (e * 4) / C::BM, col = (e * 4) % C::BM;
+                *reinterpret_cast<float4*>(&wl[row * C::BMP + col]) = g[e];
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over taps x channel quads ----
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int c4 = 0; c4 < KC / 4; ++c4) {
+                float a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = wl[(tap * KC + c4 * 4) * C::BMP + aoff + i * 16];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = il[toff[j] + c4 * 4 * C::CS + ky * C::IWP + kx];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const size_t out_plane = (size_t)p.Hout * p.Wout;
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row0 = co0 + wm * MT * 16 + i * 16 + kq * 4; // first of this lane's 4 rows
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bool ok = (opx[j] < p.Wout) && (opy[j] < p.Hout) && (row0 < p.Cout);
+            if (!ok) continue;
+            const size_t pix = (size_t)opy[j] * p.Wout + opx[j];
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_PLAIN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(row0 + r) * out_plane + pix;
+                    float x = v[r];
+                    if (p.res) x += p.res[o];
+                    p.out[o] = x;
+                    ssum[i][r] += x;
+                    ssq[i][r] += x * x;
+                }
+            } else if (EPI == EPI_UP2) { // rows (co*4 + dy*2 + dx) -> out[co][2y+dy][2x+dx]
+                const int co = row0 >> 2;
+                const size_t W2 = (size_t)p.Wout * 2;
+                float* o = p.out + (size_t)co * out_plane * 4 + (size_t)(2 * opy[j]) * W2 + 2 * opx[j];
+                *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(o + W2) = make_float2(v[2], v[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+            } else if (EPI == EPI_UP4) { // rows (co*16 + dy*4 + dx) -> out[co][4y+dy][4x+dx]
+                const int co = row0 >> 4, dy = (row0 >> 2) & 3;
+                const size_t W4 = (size_t)p.Wout * 4;
+                float* o = p.out + (size_t)co * out_plane * 16 + (size_t)(4 * opy[j] + dy) * W4 + 4 * opx[j];
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+            } else { // EPI_HEAD: rows = [cls 9 | box 63 | dir 18], outputs ordered (anchor, x, y[, code])
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + r;
+                    if (row >= p.n_rows) continue;
+                    const float x = v[r] + p.bias[row];
+                    if (row < p.n_cls) {
+                        p.out[(size_t)row * out_plane + pix] = x;
+                    } else if (row < p.n_cls + p.n_box) {
+                        const int q = row - p.n_cls, a = q / 7, k = q - a * 7;
+                        p.out_box[((size_t)a * out_plane + pix) * 7 + k] = x;
+                    } else {
+                        const int q = row - p.n_cls - p.n_box, a = q >> 1, k = q & 1;
+                        p.out_dir[((size_t)a * out_plane + pix) * 2 + k] = x;
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI != EPI_HEAD && p.stat_acc) {
+        // reduce over the 16 pixel lanes, then over the WN waves through LDS, then fp64 atomics
+        __syncthreads(); // `red` aliases nothing, but all waves must be past the MFMA loop's LDS reads
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], q = ssq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o);
+                    q += __shfl_xor(q, o);
+                }
+                if (m == 0) {
+                    const int lr = wm * MT * 16 + i * 16 + kq * 4 + r; // local row
+                    red[(wn * C::BM + lr) * 2] = s;
+                    red[(wn * C::BM + lr) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        for (int lr = tid; lr < C::BM; lr += C::THREADS) {
+            const int row = co0 + lr;
+            if (row >= p.Cout) continue;
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                s += (double)red[(w * C::BM + lr) * 2];
+                q += (double)red[(w * C::BM + lr) * 2 + 1];
+            }
+            int ch;
+            if (EPI == EPI_UP2) { if (lr & 3) continue; ch = row >> 2; }
+            else if (EPI == EPI_UP4) { if (lr & 3) continue; ch = row >> 4; }
+            else ch = row;
+            double* dst = p.stat_acc + ((size_t)(blockIdx.x % NREP) * p.stat_C + ch) * 2;
+            atomicAdd(dst, s);
+            atomicAdd(dst + 1, q);
+        }
+    }
+}
+
+// y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
+// Used for the [conv, norm, relu] head of each block, whose output is both a residual and the
+// input of the next InstanceNorm (pointpillars8_shared.py:133-137).
+__global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
+                                                       int pre, const double* __restrict__ pre_acc,
+                                                       const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
+                                                       double inv_n, float eps, double* __restrict__ stat_acc)
+{
+    const int c = blockIdx.y;
+    float sc, sh;
+    if (pre == PRE_STATS) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < NREP; ++r) {
+            s += pre_acc[((size_t)r * C + c) * 2];
+            q += pre_acc[((size_t)r * C + c) * 2 + 1];
+        }
+        double mean = s * inv_n, var = q * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        double rstd = 1.0 / sqrt(var + (double)eps);
+        sc = (float)rstd;
+        sh = (float)(-mean * rstd);
+    } else {
+        sc = pre_scale[c];
+        sh = pre_shift[c];
+    }
+    const float4* xi = reinterpret_cast<const float4*>(x + (size_t)c * HW);
+    float4* yo = reinterpret_cast<float4*>(y + (size_t)c * HW);
+    float s = 0.f, q = 0.f;
+    double ds = 0.0, dq = 0.0;
+    const int n4 = HW >> 2;
+    int it = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 v = xi[i];
+        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f);
+        v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
+        v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+        yo[i] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (++it == 8) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
+    }
+    ds += s;
+    dq += q;
+    if (!stat_acc) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ds += __shfl_xor(ds, o);
+        dq += __shfl_xor(dq, o);
+    }
+    __shared__ double rs[4], rq[4];
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = ds; rq[threadIdx.x >> 6] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* dst = stat_acc + ((size_t)(blockIdx.x % NREP) * C + c) * 2;
+        atomicAdd(dst, rs[0] + rs[1] + rs[2] + rs[3]);
+        atomicAdd(dst + 1, rq[0] + rq[1] + rq[2] + rq[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: network description, weight packing, launch plans
+// ------------------------------------------------------------------------------------------
+struct Variant { // one compiled tiling of conv_mfma
+    void (*kern)(const ConvP);
+    int bm, pw, ph, kc, threads;
+    size_t lds;
+};
+
+template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
+Variant make_variant()
+{
+    using C = ConvCfg<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
+    Variant v;
+    v.kern = conv_mfma<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
+    v.bm = C::BM; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
+    v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    return v;
+}
+
+struct Layer {
+    std::string wkey;
+    int kind;   // 0 conv3x3, 1 deconv(up), 2 head
+    int cin, cout, stride, up;
+    int level;  // pixel grid of the GEMM: 0 = H,W ; 1 = H/2 ; 2 = H/4 (input grid for deconv)
+    Variant var;
+    float* w = nullptr; // packed device weights
+    int rows = 0;       // GEMM rows (virtual channels)
+};
+
+struct NormRef { // where a consumer finds the producer's normalisation
+    int mode = PRE_RAW;
+    double* acc = nullptr;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    int C = 0;
+    double inv_n = 0.0;
+};
+
+struct pp_net {
+    std::vector<Layer> layers; // 16 convs, 3 deconvs, head in execution order
+    float* buf[3][4] = {};     // per level: 4 activation buffers [C,H,W]
+    float* up = nullptr;       // [320,H,W] pre-norm upsampled maps (concat)
+    double* stats = nullptr;   // all statistics accumulators, one memset per frame
+    size_t stats_bytes = 0;
+    float* bn_scale = nullptr; // BatchNorm variant: all folded (scale, shift) arrays
+    float* bn_shift = nullptr;
+    float* head_bias = nullptr;
+    float* ones = nullptr;
+    float* zeros = nullptr;
+};
+
+const int kC[3] = {64, 128, 256};
+
+Variant pick_variant(int kind, int stride, int up, int level, int H, int W)
+{
+    (void)H; (void)W;
+    if (kind == 2) return make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>();
+    if (kind == 1) {
+        if (up == 1) return make_variant<1, 1, 16, 1, 4, 4, 4, 1, 16, EPI_PLAIN>();
+        if (up == 2) return make_variant<1, 1, 8, 2, 2, 4, 2, 2, 16, EPI_UP2>();
+        return make_variant<1, 1, 4, 2, 2, 4, 2, 2, 16, EPI_UP4>();
+    }
+    if (level == 0) {
+        if (stride == 2) return make_variant<3, 2, 16, 1, 4, 4, 4, 1, 8, EPI_PLAIN>();
+        return make_variant<3, 1, 16, 1, 4, 4, 4, 1, 8, EPI_PLAIN>();
+    }
+    if (level == 1) {
+        if (stride == 2) return make_variant<3, 2, 8, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
+        return make_variant<3, 1, 8, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
+    }
+    if (stride == 2) return make_variant<3, 2, 4, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
+    return make_variant<3, 1, 4, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
+}
+
+int pack_layer(pp_ctx* ctx, Layer& L)
+{
+    const Variant& v = L.var;
+    const int ks = (L.kind == 0) ? 3 : 1;
+    const int taps = ks * ks;
+    auto it = ctx->host_w.find(L.wkey);
+    std::vector<float> rowsW; // [rows][cin][taps]
+    int rows = 0;
+    if (L.kind == 0) {
+        if (it == ctx->host_w.end() || (int64_t)it->second.data.size() != (int64_t)L.cout * L.cin * 9)
+            return pp_fail(ctx, PP_E_NAME, ("missing/mis-shaped weight " + L.wkey).c_str());
+        rows = L.cout;
+        rowsW = it->second.data; // [cout][cin][3][3]
+    } else if (L.kind == 1) {
+        const int u2 = L.up * L.up;
+        if (it == ctx->host_w.end() || (int64_t)it->second.data.size() != (int64_t)L.cin * L.cout * u2)
+            return pp_fail(ctx, PP_E_NAME, ("missing/mis-shaped weight " + L.wkey).c_str());
+        rows = L.cout * u2; // ConvTranspose weight [cin][cout][k][k] -> row (co*u2 + dy*u + dx)
+        rowsW.resize((size_t)rows * L.cin);
+        const std::vector<float>& s = it->second.data;
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int co = 0; co < L.cout; ++co)
+                for (int d = 0; d < u2; ++d) rowsW[((size_t)co * u2 + d) * L.cin + ci] = s[((size_t)ci * L.cout + co) * u2 + d];
+    } else {
+        rows = 96;
+        rowsW.assign((size_t)96 * L.cin, 0.f);
+        const char* names[3] = {"heads.conv_cls.weight", "heads.conv_box.weight", "heads.conv_dir.weight"};
+        const int cnt[3] = {9, 63, 18};
+        int r0 = 0;
+        for (int h = 0; h < 3; ++h) {
+            auto w = ctx->host_w.find(names[h]);
+            if (w == ctx->host_w.end() || (int64_t)w->second.data.size() != (int64_t)cnt[h] * L.cin)
+                return pp_fail(ctx, PP_E_NAME, (std::string("missing/mis-shaped weight ") + names[h]).c_str());
+            memcpy(&rowsW[(size_t)r0 * L.cin], w->second.data.data(), sizeof(float) * cnt[h] * L.cin);
+            r0 += cnt[h];
+        }
+    }
+    L.rows = rows;
+    const int nblk = pp_div_up(rows, v.bm), nchunk = L.cin / v.kc;
+    std::vector<float> pk((size_t)nblk * nchunk * taps * v.kc * v.bm, 0.f);
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int t = 0; t < taps; ++t)
+                for (int k = 0; k < v.kc; ++k)
+                    for (int mm = 0; mm < v.bm; ++mm) {
+                        const int row = b * v.bm + mm;
+                        if (row >= rows) continue;
+                        pk[((((size_t)b * nchunk + ch) * taps + t) * v.kc + k) * v.bm + mm] =
+                            rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps + t];
+                    }
+    if (L.w) (void)hipFree(L.w);
+    PP_HIP(hipMalloc((void**)&L.w, pk.size() * sizeof(float)));
+    PP_HIP(hipMemcpy(L.w, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, float* out, const float* res,
+                const NormRef& pre, double* stat_acc, int stat_C, int Hout, int Wout, hipStream_t stream,
+                float* out_box = nullptr, float* out_dir = nullptr)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.in = in; p.w = L.w; p.out = out; p.res = res;
+    p.Cin = L.cin; p.Hin = Hin; p.Win = Win;
+    p.Cout = L.rows; p.Hout = Hout; p.Wout = Wout;
+    p.pre = pre.mode; p.pre_acc = pre.acc; p.pre_scale = pre.scale; p.pre_shift = pre.shift;
+    p.pre_inv_n = pre.inv_n; p.eps = 1e-3f;
+    p.stat_acc = stat_acc; p.stat_C = stat_C;
+    p.bias = net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
+    p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
+    const Variant& v = L.var;
+    dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm));
+    const bool tag = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
+    if (tag) {
+        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+            hipEvent_t a, b;
+            PP_HIP(hipEventCreate(&a));
+            PP_HIP(hipEventCreate(&b));
+            ctx->prof_ev.push_back(a);
+            ctx->prof_ev.push_back(b);
+        }
+        ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0;
+        PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used], stream));
+    }
+    hipLaunchKernelGGL(v.kern, grid, dim3(v.threads), v.lds, stream, p);
+    if (tag) {
+        PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], stream));
+        ctx->prof_used += 2;
+    }
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+} // namespace
+
+int pp_net_create(pp_ctx* ctx)
+{
+    pp_net* net = new pp_net();
+    ctx->net = net;
+    const int H = ctx->H, W = ctx->W;
+    for (int l = 0; l < 3; ++l)
+        for (int b = 0; b < 4; ++b)
+            PP_HIP(hipMalloc((void**)&net->buf[l][b], (size_t)kC[l] * ((H >> l) + 1) * ((W >> l) + 1) * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->up, (size_t)320 * H * W * sizeof(float)));
+    // statistics accumulators: one slot of [NREP][256][2] doubles per normalisation site (<= 24 sites)
+    net->stats_bytes = (size_t)24 * NREP * 320 * 2 * sizeof(double);
+    PP_HIP(hipMalloc((void**)&net->stats, net->stats_bytes));
+    PP_HIP(hipMalloc((void**)&net->bn_scale, (size_t)24 * 320 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->bn_shift, (size_t)24 * 320 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->head_bias, 96 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->ones, 320 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->zeros, 320 * sizeof(float)));
+    std::vector<float> one(320, 1.f);
+    PP_HIP(hipMemcpy(net->ones, one.data(), 320 * sizeof(float), hipMemcpyHostToDevice));
+    PP_HIP(hipMemset(net->zeros, 0, 320 * sizeof(float)));
+    // layer list in execution order
+    int cin = 64;
+    for (int b = 0; b < 3; ++b) {
+        const int c = kC[b];
+        const int nres[3] = {1, 1, 0};
+        const int nunits = (b == 0) ? 2 : 3;
+        char key[128];
+        snprintf(key, sizeof(key), "rpn.block%d.0.weight", b + 1);
+        net->layers.push_back(Layer{key, 0, cin, c, 2, 1, b, pick_variant(0, 2, 1, b, H, W)});
+        for (int u = 0; u < nunits; ++u) {
+            const int nl = (b == 0) ? (u == 0 ? 1 : 0) : nres[u];
+            snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.2.weight", b + 1, 3 + u);
+            net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, b, H, W)});
+            if (nl == 1) {
+                snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.5.weight", b + 1, 3 + u);
+                net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, b, H, W)});
+            }
+        }
+        const int up = 1 << b;
+        snprintf(key, sizeof(key), "rpn.deconv%d.0.weight", b + 1);
+        net->layers.push_back(Layer{key, 1, c, (b == 0) ? 64 : 128, 1, up, b, pick_variant(1, 1, up, b, H, W)});
+        cin = c;
+    }
+    net->layers.push_back(Layer{"heads", 2, 320, 90, 1, 1, 0, pick_variant(2, 1, 1, 0, H, W)});
+    for (Layer& L : net->layers)
+        PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
+    return 0;
+}
+
+void pp_net_destroy(pp_ctx* ctx)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    if (!net) return;
+    for (int l = 0; l < 3; ++l)
+        for (int b = 0; b < 4; ++b)
+            if (net->buf[l][b]) (void)hipFree(net->buf[l][b]);
+    for (Layer& L : net->layers)
+        if (L.w) (void)hipFree(L.w);
+    void* ptrs[] = {net->up, net->stats, net->bn_scale, net->bn_shift, net->head_bias, net->ones, net->zeros};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    delete net;
+    ctx->net = nullptr;
+}
+
+// BatchNorm2d(eval, eps 1e-3) of the _export/_trt nets folded to (scale, shift) for norm site `site`
+static int fold_bn(pp_ctx* ctx, const std::string& prefix, int C, int site)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    auto get = [&](const char* s) -> const std::vector<float>* {
+        auto it = ctx->host_w.find(prefix + s);
+        if (it == ctx->host_w.end() || (int)it->second.data.size() != C) return nullptr;
+        return &it->second.data;
+    };
+    const std::vector<float>*g = get(".weight"), *b = get(".bias"), *rm = get(".running_mean"), *rv = get(".running_var");
+    if (!g || !b || !rm || !rv) return pp_fail(ctx, PP_E_NAME, ("missing BatchNorm tensors for " + prefix).c_str());
+    std::vector<float> sc(C), sh(C);
+    for (int c = 0; c < C; ++c) {
+        double s = (double)(*g)[c] / std::sqrt((double)(*rv)[c] + 1e-3);
+        sc[c] = (float)s;
+        sh[c] = (float)((double)(*b)[c] - (double)(*rm)[c] * s);
+    }
+    PP_HIP(hipMemcpy(net->bn_scale + (size_t)site * 320, sc.data(), C * sizeof(float), hipMemcpyHostToDevice));
+    PP_HIP(hipMemcpy(net->bn_shift + (size_t)site * 320, sh.data(), C * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Normalisation sites, numbered in execution order.  Per block b (0..2):
+//   site 8b+0: norm after the strided conv (.1)        site 8b+1+2u: Resnet2 unit u first norm (.0)
+//   site 8b+2+2u: unit u second norm (.3)              site 8b+7: norm after the deconv
+static inline int site_block(int b, int k) { return 8 * b + k; }
+
+int pp_net_commit(pp_ctx* ctx)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    for (Layer& L : net->layers) {
+        int rc = pack_layer(ctx, L);
+        if (rc) return rc;
+    }
+    float hb[96] = {0};
+    const char* names[3] = {"heads.conv_cls.bias", "heads.conv_box.bias", "heads.conv_dir.bias"};
+    const int cnt[3] = {9, 63, 18};
+    int r0 = 0;
+    for (int h = 0; h < 3; ++h) {
+        auto w = ctx->host_w.find(names[h]);
+        if (w == ctx->host_w.end() || (int)w->second.data.size() != cnt[h])
+            return pp_fail(ctx, PP_E_NAME, (std::string("missing/mis-shaped ") + names[h]).c_str());
+        memcpy(hb + r0, w->second.data.data(), sizeof(float) * cnt[h]);
+        r0 += cnt[h];
+    }
+    PP_HIP(hipMemcpy(net->head_bias, hb, sizeof(hb), hipMemcpyHostToDevice));
+    if (ctx->cfg.norm_kind == 1) {
+        for (int b = 0; b < 3; ++b) {
+            char key[128];
+            const int c = kC[b];
+            snprintf(key, sizeof(key), "rpn.block%d.1", b + 1);
+            int rc = fold_bn(ctx, key, c, site_block(b, 0));
+            if (rc) return rc;
+            const int nunits = (b == 0) ? 2 : 3;
+            for (int u = 0; u < nunits; ++u) {
+                const int nl = (u == nunits - 1) ? 0 : 1;
+                snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.0", b + 1, 3 + u);
+                if ((rc = fold_bn(ctx, key, c, site_block(b, 1 + 2 * u)))) return rc;
+                if (nl) {
+                    snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.3", b + 1, 3 + u);
+                    if ((rc = fold_bn(ctx, key, c, site_block(b, 2 + 2 * u)))) return rc;
+                }
+            }
+            snprintf(key, sizeof(key), "rpn.deconv%d.1", b + 1);
+            // deconv norms are stored contiguously at site 7 (block 0), channels [0,64),[64,192),[192,320)
+            const int coff = (b == 0) ? 0 : (b == 1 ? 64 : 192);
+            const int cc = (b == 0) ? 64 : 128;
+            pp_net* n2 = net;
+            {
+                auto get = [&](const char* s) -> const std::vector<float>* {
+                    auto it = ctx->host_w.find(std::string(key) + s);
+                    if (it == ctx->host_w.end() || (int)it->second.data.size() != cc) return nullptr;
+                    return &it->second.data;
+                };
+                const std::vector<float>*g = get(".weight"), *bb = get(".bias"), *rm = get(".running_mean"), *rv = get(".running_var");
+                if (!g || !bb || !rm || !rv) return pp_fail(ctx, PP_E_NAME, (std::string("missing BatchNorm tensors for ") + key).c_str());
+                std::vector<float> sc(cc), sh(cc);
+                for (int q = 0; q < cc; ++q) {
+                    double s = (double)(*g)[q] / std::sqrt((double)(*rv)[q] + 1e-3);
+                    sc[q] = (float)s;
+                    sh[q] = (float)((double)(*bb)[q] - (double)(*rm)[q] * s);
+                }
+                PP_HIP(hipMemcpy(n2->bn_scale + (size_t)7 * 320 + coff, sc.data(), cc * sizeof(float), hipMemcpyHostToDevice));
+                PP_HIP(hipMemcpy(n2->bn_shift + (size_t)7 * 320 + coff, sh.data(), cc * sizeof(float), hipMemcpyHostToDevice));
+            }
+        }
+    }
+    return 0;
+}
+
+namespace {
+
+// statistics slot / folded-BN arrays for a site
+NormRef norm_ref(pp_ctx* ctx, int site, int C, int coff, size_t count)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    NormRef r;
+    r.C = C;
+    if (ctx->cfg.norm_kind == 1) {
+        r.mode = PRE_AFFINE;
+        r.scale = net->bn_scale + (size_t)site * 320 + coff;
+        r.shift = net->bn_shift + (size_t)site * 320 + coff;
+    } else {
+        r.mode = PRE_STATS;
+        r.acc = net->stats + (size_t)site * NREP * 320 * 2;
+        r.inv_n = 1.0 / (double)count;
+    }
+    return r;
+}
+
+double* stat_slot(pp_ctx* ctx, int site)
+{
+    if (ctx->cfg.norm_kind == 1) return nullptr;
+    return ((pp_net*)ctx->net)->stats + (size_t)site * NREP * 320 * 2;
+}
+
+int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const NormRef& pre, double* stat, hipStream_t stream)
+{
+    int bx = pp_div_up(HW / 4, 256 * 4);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(norm_relu_stats, dim3(bx, C), dim3(256), 0, stream, x, y, C, HW, pre.mode, pre.acc, pre.scale,
+                       pre.shift, pre.inv_n, 1e-3f, stat);
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+} // namespace
+
+// canvas [64,gx,gy] -> up [320,H,W] PRE-norm (+ statistics); the head (or pp_backbone's final pass)
+// applies the last norm + ReLU.
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    const int H = ctx->H, W = ctx->W;
+    if ((H % 4) || (W % 4)) return pp_fail(ctx, PP_E_ARG, "backbone: BEV grid must be a multiple of 8 in x and y");
+    if (ctx->cfg.norm_kind == 0) PP_HIP(hipMemsetAsync(net->stats, 0, net->stats_bytes, stream));
+    NormRef raw;
+    const float* x = canvas;
+    int Hin = ctx->gx, Win = ctx->gy;
+    size_t li = 0;
+    const int up_coff[3] = {0, 64, 192};
+    for (int b = 0; b < 3; ++b) {
+        const int c = kC[b];
+        const int h = H >> b, w = W >> b;
+        const size_t cnt = (size_t)h * w;
+        float** B = net->buf[b];
+        int rc;
+        // strided conv (raw input) -> B[0] + stats(site 0)
+        if ((rc = launch_conv(ctx, net->layers[li++], x, Hin, Win, B[0], nullptr, raw, stat_slot(ctx, site_block(b, 0)), c, h, w, stream))) return rc;
+        // y = relu(norm(B[0])) -> B[1] + stats(site 1) (the first Resnet2 unit's leading norm)
+        if ((rc = launch_norm_relu(ctx, B[0], B[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
+                                   stat_slot(ctx, site_block(b, 1)), stream))) return rc;
+        float* cur = B[1];
+        float* spare[3] = {B[0], B[2], B[3]};
+        const int nunits = (b == 0) ? 2 : 3;
+        for (int u = 0; u < nunits; ++u) {
+            const int nl = (u == nunits - 1) ? 0 : 1;
+            const bool last = (u == nunits - 1);
+            float* t1 = spare[0];
+            float* t2 = spare[1];
+            // stats for the NEXT unit's leading norm are produced by this unit's output
+            double* out_stat = last ? nullptr : stat_slot(ctx, site_block(b, 1 + 2 * (u + 1)));
+            if (nl == 1) {
+                if ((rc = launch_conv(ctx, net->layers[li++], cur, h, w, t1, nullptr, norm_ref(ctx, site_block(b, 1 + 2 * u), c, 0, cnt),
+                                      stat_slot(ctx, site_block(b, 2 + 2 * u)), c, h, w, stream))) return rc;
+                if ((rc = launch_conv(ctx, net->layers[li++], t1, h, w, t2, cur, norm_ref(ctx, site_block(b, 2 + 2 * u), c, 0, cnt),
+                                      out_stat, c, h, w, stream))) return rc;
+                // rotate buffers: t2 becomes current, old current + t1 are free
+                spare[1] = cur;
+                cur = t2;
+            } else {
+                if ((rc = launch_conv(ctx, net->layers[li++], cur, h, w, t1, cur, norm_ref(ctx, site_block(b, 1 + 2 * u), c, 0, cnt),
+                                      out_stat, c, h, w, stream))) return rc;
+                spare[0] = cur;
+                cur = t1;
+            }
+        }
+        // deconv on the raw block output -> up[coff..] + stats (site 7, channel offset)
+        {
+            const Layer& L = net->layers[li++];
+            double* st = stat_slot(ctx, 7);
+            // deconv statistics live in one 320-channel slot; pass the slot shifted to this map's channels
+            double* st_off = st ? st + (size_t)up_coff[b] * 2 : nullptr;
+            (void)st_off;
+            if ((rc = launch_conv(ctx, L, cur, h, w, net->up + (size_t)up_coff[b] * H * W, nullptr, raw, st ? st + (size_t)up_coff[b] * 2 : nullptr,
+                                  320, h, w, stream))) return rc;
+        }
+        x = cur;
+        Hin = h;
+        Win = w;
+    }
+    return 0;
+}
+
+static int pp_head_impl(pp_ctx* ctx, const float* in, const NormRef& pre, float* cls, float* box, float* dir, hipStream_t stream)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    return launch_conv(ctx, net->layers.back(), in, ctx->H, ctx->W, cls, nullptr, pre, nullptr, 0, ctx->H, ctx->W, stream, box, dir);
+}
+
+int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, hipStream_t stream)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    NormRef pre = norm_ref(ctx, 7, 320, 0, (size_t)ctx->H * ctx->W);
+    return pp_head_impl(ctx, net->up, pre, cls, box, dir, stream);
+}
+
+extern "C" int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, void* stream_)
+{
+    if (!ctx) return PP_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_backbone: weights not committed");
+    if (!canvas || !rpn_out) return pp_fail(ctx, PP_E_ARG, "pp_backbone: null pointer");
+    int rc = pp_run_backbone(ctx, canvas, stream);
+    if (rc) return rc;
+    pp_net* net = (pp_net*)ctx->net;
+    const int HW = ctx->H * ctx->W;
+    // stand-alone API: materialise relu(norm(up)) as the reference's RPN.forward returns it
+    return launch_norm_relu(ctx, net->up, rpn_out, 320, HW, norm_ref(ctx, 7, 320, 0, (size_t)HW), nullptr, stream);
+}
+
+extern "C" int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box, float* dir, void* stream_)
+{
+    if (!ctx) return PP_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_head: weights not committed");
+    if (!rpn_out || !cls || !box || !dir) return pp_fail(ctx, PP_E_ARG, "pp_head: null pointer");
+    NormRef raw; // rpn_out is already normalised + ReLU'd
+    return pp_head_impl(ctx, rpn_out, raw, cls, box, dir, stream);
+}
+
+extern "C" int pp_profile_begin(pp_ctx* ctx)
+{
+    if (!ctx) return PP_E_ARG;
+    ctx->prof_on = true;
+    ctx->prof_used = 0;
+    return 0;
+}
+
+extern "C" int pp_profile_end(pp_ctx* ctx, double* avg_ms, int32_t* launches, double* flops)
+{
+    if (!ctx || !avg_ms || !launches || !flops) return PP_E_ARG;
+    ctx->prof_on = false;
+    double tot = 0.0;
+    const size_t n = ctx->prof_used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        PP_HIP(hipEventSynchronize(ctx->prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        PP_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *avg_ms = n ? tot / (double)n : 0.0;
+    *launches = (int32_t)n;
+    *flops = ctx->prof_flops;
+    ctx->prof_used = 0;
+    return 0;
+}

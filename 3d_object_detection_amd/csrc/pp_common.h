@@ -1,0 +1,85 @@
+// Internal definitions shared by the HIP sources of libpp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/pp_hip.h"
+
+#define PP_EMPTY 0x7F7F7F7F  // "no index" sentinel; hipMemsetAsync(…, 0x7F, …) produces it
+
+#define PP_HIP(call)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return pp_fail_hip(ctx, e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+struct pp_tensor_h {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+// one conv-like layer after packing (see conv.hip)
+struct pp_layer {
+    float* w = nullptr;        // packed weights on device
+    int cin = 0, cout = 0;     // logical channels (cout = virtual channels for deconv)
+    int ks = 1, stride = 1;    // conv kernel / stride (deconv: ks = 1, up = upsample factor)
+    int up = 1;
+    float* bn_scale = nullptr; // BatchNorm variant: per-input-channel affine folded for the prologue
+    float* bn_shift = nullptr;
+};
+
+struct pp_ctx {
+    pp_config cfg;
+    int device = 0;
+    std::string err;
+    // ---- geometry ----
+    int gx = 0, gy = 0, H = 0, W = 0; // BEV grid and level-1 feature map (H = gx/2 along x, W = gy/2 along y)
+    int64_t A = 0;                    // anchors
+    // ---- voxeliser workspace ----
+    int32_t* cell_first = nullptr; // [gx*gy*gz] first point index per cell
+    int32_t* pt_cell = nullptr;    // [max_points]
+    int32_t* pt_rank = nullptr;    // [max_points] pillar rank of first points
+    int32_t* wave_cnt = nullptr;   // [max_points/64 + 1]
+    int32_t* slots = nullptr;      // [max_voxels*T] ordered point indices per pillar
+    int32_t* vox_scalars = nullptr; // [4]: istar, P_all
+    // ---- anchor mask workspace ----
+    int32_t* occ = nullptr;        // [gx*gy] occupancy -> summed-area table
+    float* anchors = nullptr;      // [A,7]
+    int32_t* rect_x = nullptr;     // separable cell rectangles: [types, H, 2] (minx,maxx) / [types, W, 2] (miny,maxy)
+    int32_t* rect_y = nullptr;
+    int32_t* rects = nullptr;      // full [A,4] table (fallback when not separable)
+    int rect_separable = 0;
+    // ---- frame buffers (pp_infer_frame) ----
+    float* f_voxels = nullptr; int32_t* f_coors = nullptr; int32_t* f_npts = nullptr; int32_t* f_num = nullptr;
+    float* f_feat = nullptr; float* f_canvas = nullptr; uint8_t* f_mask = nullptr;
+    float* f_cls = nullptr; float* f_box = nullptr; float* f_dir = nullptr;
+    // ---- network ----
+    std::map<std::string, pp_tensor_h> host_w;
+    bool weights_ready = false;
+    float* pfn_w = nullptr;     // [9][64] transposed
+    float* pfn_scale = nullptr; // [64]
+    float* pfn_shift = nullptr; // [64]
+    void* net = nullptr;        // opaque pp_net (conv.hip)
+    void* post = nullptr;       // opaque pp_post workspace (postprocess.hip)
+    // ---- measurement (pp_profile_begin/end) ----
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev; // start/stop pairs
+    size_t prof_used = 0;
+    double prof_flops = 0.0;
+};
+
+int pp_fail_hip(pp_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
+int pp_fail(pp_ctx* ctx, int code, const char* msg);
+
+// stage entry points implemented per file (all enqueue on stream, no sync)
+int pp_net_create(pp_ctx* ctx);
+void pp_net_destroy(pp_ctx* ctx);
+int pp_net_commit(pp_ctx* ctx);
+int pp_post_create(pp_ctx* ctx);
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream);          // canvas -> pre-norm [320,H,W] + stats
+int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, hipStream_t stream); // norm+ReLU fused in the prologue
+void pp_post_destroy(pp_ctx* ctx);
+
+static inline int pp_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,187 @@
+// Points -> pillars, bit-exact with the reference's sequential loop
+// (framework/voxel_generator.py:82-106) but order-independent in execution:
+//
+//   K1  cell id per point (IEEE fp32 floorf((p-off)/vs), true division) + atomicMin of the
+//       point index into cell_first[cell]              -> first point of every cell
+//   K2  first-point flags -> per-wave popcounts (64-wide ballot)
+//   K3  rank of each first point = exclusive prefix of the flags = pillar id in order of first
+//       appearance; the point that would open pillar #max_voxels is the reference's `break`
+//       (:96-97): i* = its index, every point >= i* is dropped
+//   K4  ordered slotting without sorting: each point pushes its index through the pillar's T
+//       slots with atomicMin, carrying the displaced (larger) index onward.  Whatever the
+//       interleaving, slot s ends up holding the (s+1)-th smallest index of the cell, i.e.
+//       the first T points in stream order (:103-105)
+//   K5  gather points into voxels[P,T,F] (zero padded) and count filled slots
+//
+// All HBM traffic is the raw cloud (16 B/point) + the [P,T,F] output; cell_first (2.56 MB at
+// 800^2) and the slot table live in L2/Infinity Cache.
+#include "pp_common.h"
+
+namespace {
+
+__device__ __forceinline__ int cell_of(const float* __restrict__ p, float ox, float oy, float oz, float vx,
+                                       float vy, float vz, int gx, int gy, int gz, int& cx, int& cy, int& cz)
+{
+    // __fdiv_rn / __fsub_rn: no reciprocal, no contraction -- boundaries must match numpy fp32
+    float fx = floorf(__fdiv_rn(__fsub_rn(p[0], ox), vx));
+    float fy = floorf(__fdiv_rn(__fsub_rn(p[1], oy), vy));
+    float fz = floorf(__fdiv_rn(__fsub_rn(p[2], oz), vz));
+    bool in = (fx >= 0.f) & (fx < (float)gx) & (fy >= 0.f) & (fy < (float)gy) & (fz >= 0.f) & (fz < (float)gz);
+    if (!in) return -1;
+    cx = (int)fx; cy = (int)fy; cz = (int)fz;
+    return (cx * gy + cy) * gz + cz;
+}
+
+__global__ void __launch_bounds__(256) vox_cell_first(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+                                                      int32_t* __restrict__ pt_cell, int32_t* __restrict__ cell_first)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cx, cy, cz;
+    int c = cell_of(pts + (size_t)i * nfeat, cfg.offset[0], cfg.offset[1], cfg.offset[2], cfg.voxel_size[0],
+                    cfg.voxel_size[1], cfg.voxel_size[2], cfg.grid_size[0], cfg.grid_size[1], cfg.grid_size[2], cx, cy, cz);
+    pt_cell[i] = c;
+    if (c >= 0) atomicMin(&cell_first[c], i);
+}
+
+__global__ void __launch_bounds__(256) vox_flag_count(const int32_t* __restrict__ pt_cell,
+                                                      const int32_t* __restrict__ cell_first, int n,
+                                                      int32_t* __restrict__ wave_cnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool flag = false;
+    if (i < n) {
+        int c = pt_cell[i];
+        flag = (c >= 0) && (cell_first[c] == i);
+    }
+    unsigned long long b = __ballot(flag);
+    if ((threadIdx.x & 63) == 0) wave_cnt[i >> 6] = __popcll(b);
+}
+
+// Each wave derives its own exclusive offset by summing the counts of all earlier waves
+// (nw <= a few thousand: cheaper than a separate scan launch).
+__global__ void __launch_bounds__(256) vox_rank(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+                                                const int32_t* __restrict__ pt_cell,
+                                                const int32_t* __restrict__ cell_first,
+                                                const int32_t* __restrict__ wave_cnt, int32_t* __restrict__ pt_rank,
+                                                int32_t* __restrict__ coors, int32_t* __restrict__ scalars,
+                                                int32_t* __restrict__ num_pillars)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    int w = i >> 6;
+    int nw = (n + 63) >> 6;
+    int part = 0, tot = 0;
+    for (int k = lane; k < nw; k += 64) {
+        int v = wave_cnt[k];
+        tot += v;
+        if (k < w) part += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        part += __shfl_xor(part, o);
+        tot += __shfl_xor(tot, o);
+    }
+    bool flag = false;
+    int c = -1;
+    if (i < n) {
+        c = pt_cell[i];
+        flag = (c >= 0) && (cell_first[c] == i);
+    }
+    unsigned long long b = __ballot(flag);
+    int rank = part + __popcll(b & ((1ull << lane) - 1ull));
+    if (flag) {
+        pt_rank[i] = rank;
+        if (rank < cfg.max_voxels) {
+            int gy = cfg.grid_size[1], gz = cfg.grid_size[2];
+            int cz = c % gz, cy = (c / gz) % gy, cx = c / (gz * gy);
+            coors[3 * rank + 0] = cx;
+            coors[3 * rank + 1] = cy;
+            coors[3 * rank + 2] = cz;
+        } else if (rank == cfg.max_voxels) {
+            scalars[0] = i; // i*: the reference breaks here
+        }
+    }
+    if (i == 0) {
+        scalars[1] = tot;
+        *num_pillars = tot < cfg.max_voxels ? tot : cfg.max_voxels;
+    }
+}
+
+__global__ void __launch_bounds__(256) vox_insert(int n, pp_config cfg, const int32_t* __restrict__ pt_cell,
+                                                  const int32_t* __restrict__ cell_first,
+                                                  const int32_t* __restrict__ pt_rank,
+                                                  const int32_t* __restrict__ scalars, int32_t* __restrict__ slots)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i >= scalars[0]) return;
+    int c = pt_cell[i];
+    if (c < 0) return;
+    int r = pt_rank[cell_first[c]];
+    if (r >= cfg.max_voxels) return; // unreachable for i < i*, kept as a guard
+    int32_t* s = slots + (size_t)r * cfg.max_num_points;
+    int x = i;
+    for (int k = 0; k < cfg.max_num_points; ++k) {
+        int old = atomicMin(&s[k], x);
+        x = old > x ? old : x; // the larger of the two moves on
+        if (x >= PP_EMPTY) break;
+    }
+}
+
+__global__ void __launch_bounds__(256) vox_gather(const float* __restrict__ pts, int nfeat, pp_config cfg,
+                                                  const int32_t* __restrict__ slots,
+                                                  const int32_t* __restrict__ num_pillars, float* __restrict__ voxels,
+                                                  int32_t* __restrict__ npts)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x; // (pillar, slot)
+    int T = cfg.max_num_points;
+    int p = t / T, k = t - p * T;
+    if (p >= *num_pillars) return;
+    int idx = slots[t];
+    bool have = idx < PP_EMPTY;
+    float* dst = voxels + (size_t)t * nfeat;
+    if (nfeat == 4) {
+        float4 v = have ? *reinterpret_cast<const float4*>(pts + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dst) = v;
+    } else {
+        for (int f = 0; f < nfeat; ++f) dst[f] = have ? pts[(size_t)idx * nfeat + f] : 0.f;
+    }
+    if (k == 0) {
+        int cnt = 0;
+        for (int q = 0; q < T; ++q) cnt += slots[(size_t)p * T + q] < PP_EMPTY;
+        npts[p] = cnt;
+    }
+}
+
+} // namespace
+
+extern "C" int pp_voxelize(pp_ctx* ctx, const float* pts, int n, int nfeat, float* voxels, int32_t* coors,
+                           int32_t* npts, int32_t* num_pillars, void* stream_)
+{
+    if (!ctx) return PP_E_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const pp_config& cfg = ctx->cfg;
+    if (n < 0 || n > cfg.max_points) return pp_fail(ctx, PP_E_ARG, "pp_voxelize: n exceeds cfg.max_points");
+    if (nfeat != cfg.num_point_features || nfeat < 3) return pp_fail(ctx, PP_E_ARG, "pp_voxelize: nfeat mismatch");
+    if (!voxels || !coors || !npts || !num_pillars || (n > 0 && !pts)) return pp_fail(ctx, PP_E_ARG, "pp_voxelize: null pointer");
+    if (n == 0) {
+        PP_HIP(hipMemsetAsync(num_pillars, 0, sizeof(int32_t), stream));
+        return 0;
+    }
+    size_t cells = (size_t)cfg.grid_size[0] * cfg.grid_size[1] * cfg.grid_size[2];
+    PP_HIP(hipMemsetAsync(ctx->cell_first, 0x7F, cells * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(ctx->slots, 0x7F, (size_t)cfg.max_voxels * cfg.max_num_points * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(ctx->vox_scalars, 0x7F, 4 * sizeof(int32_t), stream));
+    int nb = pp_div_up(n, 256);
+    hipLaunchKernelGGL(vox_cell_first, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, ctx->pt_cell, ctx->cell_first);
+    hipLaunchKernelGGL(vox_flag_count, dim3(nb), dim3(256), 0, stream, ctx->pt_cell, ctx->cell_first, n, ctx->wave_cnt);
+    hipLaunchKernelGGL(vox_rank, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, ctx->pt_cell, ctx->cell_first,
+                       ctx->wave_cnt, ctx->pt_rank, coors, ctx->vox_scalars, num_pillars);
+    hipLaunchKernelGGL(vox_insert, dim3(nb), dim3(256), 0, stream, n, cfg, ctx->pt_cell, ctx->cell_first, ctx->pt_rank,
+                       ctx->vox_scalars, ctx->slots);
+    int nt = cfg.max_voxels * cfg.max_num_points;
+    hipLaunchKernelGGL(vox_gather, dim3(pp_div_up(nt, 256)), dim3(256), 0, stream, pts, nfeat, cfg, ctx->slots, num_pillars,
+                       voxels, npts);
+    PP_HIP(hipGetLastError());
+    return 0;
+}

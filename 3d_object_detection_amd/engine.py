@@ -1,0 +1,277 @@
+"""Engine: one pp_ctx (libpp_hip.so) per config dict / GPU, shared by the drop-in classes.
+
+PyTorch-ROCm tensors are containers only: every method hands `tensor.data_ptr()` and the
+current HIP stream to the C ABI (include/pp_hip.h) and returns device tensors.  Nothing
+here computes on the CPU except the one-off geometry / anchor tables that the reference
+also builds in __init__ (voxel_generator.py:6-26, anchor_assigner.py:221-298).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F32 = np.float32
+
+# class table hard-coded by the reference at anchor_assigner.py:222-245 (config['detect_class'] is overwritten there)
+DETECT_CLASSES = ["vehicle", "pedestrian", "cyclist"]
+CLASS_TABLE = {
+    "vehicle": dict(sizes=[[4.6, 2.10, 1.8], [7.5, 2.6, 2.9], [12.6, 2.9, 3.8]], rotations=[0, 1.5707963267948966],
+                    matched_threshold=0.6, unmatched_threshold=0.45),
+    "pedestrian": dict(sizes=[[0.96874749, 0.9645992, 1.81212425]], rotations=[0],
+                       matched_threshold=0.45, unmatched_threshold=0.25),
+    "cyclist": dict(sizes=[[2.02032733, 0.98075615, 1.72027404]], rotations=[0, 1.5707963267948966],
+                    matched_threshold=0.5, unmatched_threshold=0.25),
+}
+NUM_ANCHOR_PER_LOC = 9
+
+
+def snap_geometry(config):
+    """VoxelGenerator.__init__ arithmetic (voxel_generator.py:6-26): snap the range to whole cells."""
+    dr = np.array(config["detection_range"], dtype=F32)
+    center = (dr[3:] + dr[:3]) / 2
+    vs = np.array(config["voxel_size"], dtype=F32)
+    grid = ((dr[3:] - dr[:3]) / vs).astype(np.int32)
+    range_diff = grid.astype(F32) * vs
+    offset = center - range_diff / 2
+    return vs, offset, grid, range_diff, np.concatenate((offset, offset + range_diff), axis=0)
+
+
+def _limit_period(val, offset=0.5, period=np.pi):
+    return val - np.floor(val / period + offset) * period
+
+
+def build_anchor_tables(offset, range_diff, grid_size, voxel_size):
+    """Host mirror of AnchorAssigner.__init__/.generate (anchor_assigner.py:247-320) plus
+    rbbox2d_to_near_bbox / get_anchor_coor (box_np_ops.py:308-320,288-305).  The reference
+    hard-codes a 400x400 feature map; here it is grid/2 (the same for eight_20cm)."""
+    fmap = np.array([int(grid_size[0]) // 2, int(grid_size[1]) // 2, 1], dtype=F32)
+    strides = range_diff / fmap
+    centre0 = offset + strides / 2
+    xs = np.arange(int(fmap[0]), dtype=F32) * strides[0] + centre0[0]
+    ys = np.arange(int(fmap[1]), dtype=F32) * strides[1] + centre0[1]
+    tables, class_masks, start = [], {}, 0
+    for name in DETECT_CLASSES:
+        t = CLASS_TABLE[name]
+        parts = []
+        for size in t["sizes"]:
+            zc = (np.arange(1, dtype=F32) * strides[2] + size[2] / 2)[0]
+            for rot in t["rotations"]:
+                a = np.empty((xs.size, ys.size, 7), dtype=F32)
+                a[..., 0] = xs[:, None]
+                a[..., 1] = ys[None, :]
+                a[..., 2] = zc
+                a[..., 3:6] = np.array(size, dtype=F32)
+                a[..., 6] = F32(rot)
+                parts.append(a.reshape(-1, 7))
+        tab = np.concatenate(parts)
+        tables.append(tab)
+        class_masks[name] = [start, start + tab.shape[0]]
+        start += tab.shape[0]
+    anchors = np.ascontiguousarray(np.concatenate(tables))
+    rots = anchors[:, 6]
+    swap = np.abs(_limit_period(rots, 0.5, np.pi)) > np.pi / 4
+    dx = np.where(swap, anchors[:, 4], anchors[:, 3])
+    dy = np.where(swap, anchors[:, 3], anchors[:, 4])
+    bv = np.stack([anchors[:, 0] - dx / 2, anchors[:, 1] - dy / 2, anchors[:, 0] + dx / 2, anchors[:, 1] + dy / 2],
+                  axis=1).astype(F32)
+    vs = np.asarray(voxel_size, dtype=F32)
+    off = np.asarray(offset, dtype=F32)
+    rects = np.empty(bv.shape, dtype=np.int32)
+    rects[:, 0] = np.maximum(np.floor((bv[:, 0] - off[0]) / vs[0]).astype(np.int32), 0)
+    rects[:, 1] = np.maximum(np.floor((bv[:, 1] - off[1]) / vs[1]).astype(np.int32), 0)
+    rects[:, 2] = np.minimum(np.floor((bv[:, 2] - off[0]) / vs[0]).astype(np.int32), int(grid_size[0]) - 1)
+    rects[:, 3] = np.minimum(np.floor((bv[:, 3] - off[1]) / vs[1]).astype(np.int32), int(grid_size[1]) - 1)
+    return anchors, bv, np.ascontiguousarray(rects), class_masks
+
+
+_DUMMY = {}
+
+
+def _ptr(t):
+    """Device pointer of a tensor; empty tensors (data_ptr() == 0) map to a 256-byte dummy so the
+    C ABI's null checks only fire on real mistakes."""
+    if t is None:
+        return None
+    if t.numel() == 0:
+        d = _DUMMY.get(t.device)
+        if d is None:
+            d = _DUMMY[t.device] = torch.zeros(64, dtype=torch.int32, device=t.device)
+        return ctypes.c_void_p(d.data_ptr())
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """Owns a pp_ctx.  Created lazily through engine_for(config)."""
+
+    def __init__(self, config, device_index=0, norm="instance", max_points=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("3d_object_detection_amd needs a ROCm GPU: the HIP path has no CPU fallback")
+        if "grid_size" in config and "detection_offset" in config:
+            vs = np.asarray(config["voxel_size"], dtype=F32)
+            offset = np.asarray(config["detection_offset"], dtype=F32)
+            grid = np.asarray(config["grid_size"], dtype=np.int32)
+            range_diff = np.asarray(config["detection_range_diff"], dtype=F32)
+        else:
+            vs, offset, grid, range_diff, _ = snap_geometry(config)
+        self.voxel_size, self.offset, self.grid_size, self.range_diff = vs, offset, grid, range_diff
+        self.max_voxels = int(config["max_voxels"])
+        self.T = int(config["max_num_points"])
+        self.F = int(config.get("num_point_features", 4))
+        self.device = torch.device("cuda", device_index)
+        self.anchors_np, self.anchors_bv, self.rects_np, self.class_masks = build_anchor_tables(offset, range_diff, grid, vs)
+        self.A = self.anchors_np.shape[0]
+        self.H, self.W = int(grid[0]) // 2, int(grid[1]) // 2
+        c = _lib.PPConfig()
+        for i in range(3):
+            c.voxel_size[i] = float(vs[i])
+            c.offset[i] = float(offset[i])
+            c.grid_size[i] = int(grid[i])
+        c.max_voxels, c.max_num_points, c.num_point_features = self.max_voxels, self.T, self.F
+        c.max_points = int(max_points or config.get("max_points", 1 << 18))
+        c.num_anchor_per_loc = NUM_ANCHOR_PER_LOC
+        c.num_classes = len(self.class_masks)
+        for i, (s, e) in enumerate(self.class_masks.values()):
+            c.class_begin[i], c.class_end[i] = s, e
+        for i, v in enumerate(config["center_limit"]):
+            c.center_limit[i] = float(v)
+        c.norm_kind = 0 if norm == "instance" else 1
+        c.nms_pre_max, c.nms_post_max = 1000, 300          # inference.py:13-14
+        c.nms_iou_threshold, c.score_threshold = 0.1, 0.05  # inference.py:15,19
+        self.cfg = c
+        self.max_points = c.max_points
+        self.norm = norm
+        with torch.cuda.device(self.device):
+            self.ctx = self.lib.pp_create(device_index, ctypes.byref(c))
+            if not self.ctx:
+                raise RuntimeError("pp_create failed: " + self.lib.pp_last_error(None).decode())
+            _lib.check(self.lib.pp_set_anchors(self.ctx, self.anchors_np.ctypes.data_as(ctypes.c_void_p),
+                                               self.rects_np.ctypes.data_as(ctypes.c_void_p), self.A), self.ctx, "pp_set_anchors")
+        self.weights_loaded = False
+        self._P1 = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.pp_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=F32)
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(self.lib.pp_load_weights(self.ctx, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim),
+                       self.ctx, "pp_load_weights(" + k + ")")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_commit_weights(self.ctx), self.ctx, "pp_commit_weights")
+        self.weights_loaded = True
+
+    # ------------------------------------------------------------------ stages (device tensors in/out)
+    def _t(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def num_tensor(self, p):
+        """device int32[1] holding a host-known pillar count."""
+        return torch.full((1,), int(p), dtype=torch.int32, device=self.device)
+
+    def voxelize(self, points):
+        """points f32[N,F] cuda -> (voxels[max_voxels,T,F], coors[max_voxels,3], npts[max_voxels], num[1]) on device."""
+        assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+        n = int(points.shape[0])
+        voxels = self._t((self.max_voxels, self.T, self.F), torch.float32)
+        coors = self._t((self.max_voxels, 3), torch.int32)
+        npts = self._t((self.max_voxels,), torch.int32)
+        num = self._t((1,), torch.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_voxelize(self.ctx, _ptr(points), n, int(points.shape[1]) if points.dim() == 2 else self.F,
+                                            _ptr(voxels), _ptr(coors), _ptr(npts), _ptr(num), _stream()), self.ctx, "pp_voxelize")
+        return voxels, coors, npts, num
+
+    def anchor_mask(self, coors, num):
+        mask = self._t((self.A,), torch.uint8)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_anchor_mask(self.ctx, _ptr(coors), _ptr(num), _ptr(mask), _stream()), self.ctx, "pp_anchor_mask")
+        return mask
+
+    def pfn(self, voxels, coors, npts, num):
+        feat = self._t((max(int(voxels.shape[0]), 1), 64), torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_pfn(self.ctx, _ptr(voxels), _ptr(coors), _ptr(npts), _ptr(num), _ptr(feat), _stream()),
+                       self.ctx, "pp_pfn")
+        return feat
+
+    def scatter(self, feat, coors, num):
+        canvas = self._t((1, 64, int(self.grid_size[0]), int(self.grid_size[1])), torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_scatter(self.ctx, _ptr(feat), _ptr(coors), _ptr(num), _ptr(canvas), _stream()), self.ctx, "pp_scatter")
+        return canvas
+
+    def backbone(self, canvas):
+        out = self._t((1, 320, self.H, self.W), torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_backbone(self.ctx, _ptr(canvas), _ptr(out), _stream()), self.ctx, "pp_backbone")
+        return out
+
+    def head(self, rpn_out):
+        cls = self._t((1, self.A, 1), torch.float32)
+        box = self._t((1, self.A, 7), torch.float32)
+        dr = self._t((1, self.A, 2), torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_head(self.ctx, _ptr(rpn_out), _ptr(cls), _ptr(box), _ptr(dr), _stream()), self.ctx, "pp_head")
+        return cls, box, dr
+
+    def postprocess(self, cls, box, dr, mask, nms_mode=0):
+        det = torch.zeros((self.cfg.num_classes * self.cfg.nms_post_max, 9), dtype=torch.float32, device=self.device)
+        cnt = torch.zeros((1 + _lib.PP_MAX_CLASSES,), dtype=torch.int32, device=self.device)
+        m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_postprocess(self.ctx, _ptr(cls), _ptr(box), _ptr(dr), _ptr(m), _ptr(det), _ptr(cnt),
+                                               int(nms_mode), _stream()), self.ctx, "pp_postprocess")
+        return det, cnt
+
+    def infer_frame(self, points, det=None, cnt=None, nms_mode=0):
+        """Fused path: one call, no host sync.  points f32[N,4] on the device."""
+        if det is None:
+            det = torch.zeros((self.cfg.num_classes * self.cfg.nms_post_max, 9), dtype=torch.float32, device=self.device)
+            cnt = torch.zeros((1 + _lib.PP_MAX_CLASSES,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_infer_frame(self.ctx, _ptr(points), int(points.shape[0]), _ptr(det), _ptr(cnt), int(nms_mode),
+                                               _stream()), self.ctx, "pp_infer_frame")
+        return det, cnt
+
+    def profile_begin(self):
+        _lib.check(self.lib.pp_profile_begin(self.ctx), self.ctx, "pp_profile_begin")
+
+    def profile_end(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
+        _lib.check(self.lib.pp_profile_end(self.ctx, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.ctx, "pp_profile_end")
+        return ms.value, n.value, fl.value
+
+
+def engine_for(config, norm=None):
+    """The engine shared by the drop-in objects built from one config dict (they all receive the
+    same mutable dict in the reference too, train.py:188-196)."""
+    eng = config.get("_pp_engine")
+    want = norm or config.get("_pp_norm", "instance")
+    if eng is None or eng.norm != want:
+        dev = config.get("device", torch.device("cuda:0"))
+        idx = dev.index if isinstance(dev, torch.device) and dev.index is not None else 0
+        old = eng
+        eng = Engine(config, device_index=idx, norm=want)
+        if old is not None and old.weights_loaded:
+            pass
+        config["_pp_engine"] = eng
+        config["_pp_norm"] = want
+    return eng

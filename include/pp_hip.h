@@ -1,0 +1,127 @@
+/* pp_hip.h -- C ABI of libpp_hip.so: the MI355X (gfx950) PointPillars inference hot path.
+ *
+ * The reference (1005088h/3d_object_detection) is pure Python and has no FFI; the
+ * boundary it offers is the Python call surface of train.py:192-196,224-230.  Each entry
+ * point below is what a ctypes binding for that surface binds (INTEGRATION.md shows the
+ * stubs); the "replaces" note cites the reference function it stands in for.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _h (host);
+ *  - the caller allocates every output; functions only enqueue work on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream) and never synchronise,
+ *    except where noted;
+ *  - return value: 0 = ok, <0 = -(hipError_t), >0 = argument/state error (PP_E_*);
+ *    pp_last_error(ctx) returns a static, human readable message for the last failure;
+ *  - one pp_ctx per GPU/stream; a ctx is not re-entrant, different ctxs are independent.
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_MAX_CLASSES 8
+#define PP_E_ARG 1      /* bad argument (null pointer, size out of range) */
+#define PP_E_STATE 2    /* weights / anchors not loaded yet */
+#define PP_E_NAME 3     /* unknown weight name or wrong shape */
+
+typedef struct pp_ctx pp_ctx;
+
+/* Geometry and limits.  Filled by the Python VoxelGenerator/AnchorAssigner mirrors from
+ * the same config keys the reference reads (voxel_generator.py:6-26, inference.py:13-19). */
+typedef struct pp_config {
+    float voxel_size[3];
+    float offset[3];          /* detection_offset */
+    int32_t grid_size[3];     /* gx, gy, gz (gz must be 1 for the BEV path) */
+    int32_t max_voxels;
+    int32_t max_num_points;   /* T */
+    int32_t num_point_features; /* F (4) */
+    int32_t max_points;       /* capacity of the per-point workspace (N upper bound) */
+    int32_t num_anchor_per_loc; /* 9 */
+    int32_t num_classes;      /* 3 */
+    int32_t class_begin[PP_MAX_CLASSES]; /* anchor index ranges, class_masks of anchor_assigner.py:289 */
+    int32_t class_end[PP_MAX_CLASSES];
+    double center_limit[6];   /* compared in fp64 like inference.py:105-109 (python floats) */
+    int32_t norm_kind;        /* 0 = InstanceNorm2d(eps 1e-3) backbone (_shared), 1 = BatchNorm2d (_export/_trt) */
+    int32_t nms_pre_max;      /* 1000 */
+    int32_t nms_post_max;     /* 300 (<= 1024) */
+    float nms_iou_threshold;  /* 0.1  */
+    float score_threshold;    /* 0.05 */
+} pp_config;
+
+/* Lifetime.  pp_create allocates all device workspace for the configured sizes. */
+pp_ctx* pp_create(int device, const pp_config* cfg);
+void pp_destroy(pp_ctx* ctx);
+const char* pp_last_error(pp_ctx* ctx); /* ctx may be NULL: last pp_create failure */
+
+/* Weights by state_dict key (replaces net.load_state_dict, train.py:201-202; key names of
+ * networks/pointpillars8_shared.py:346-357).  host_ptr is fp32, contiguous.  Call
+ * pp_commit_weights once after the last tensor: it folds BN, repacks for the kernels
+ * and uploads.  Synchronous. */
+int pp_load_weights(pp_ctx* ctx, const char* name, const void* host_ptr_h, const int64_t* shape_h, int ndim);
+int pp_commit_weights(pp_ctx* ctx);
+
+/* Anchor table built by the host mirror of AnchorAssigner.__init__ (anchor_assigner.py:221-298):
+ * anchors f32[A,7], cell rectangles i32[A,4] from get_anchor_coor (box_np_ops.py:288-305). Synchronous. */
+int pp_set_anchors(pp_ctx* ctx, const float* anchors_h, const int32_t* anchor_rects_h, int64_t num_anchors);
+
+/* replaces VoxelGenerator.generate / points_to_voxels (voxel_generator.py:28-40,82-106).
+ * pts f32[n,nfeat] -> voxels f32[max_voxels,T,F] (rows >= *num_pillars untouched), coors i32[max_voxels,3]
+ * (x,y,z), npts i32[max_voxels], num_pillars i32[1]. Bit-exact incl. the max_voxels break. */
+int pp_voxelize(pp_ctx* ctx, const float* pts, int n, int nfeat, float* voxels, int32_t* coors,
+                int32_t* npts, int32_t* num_pillars, void* stream);
+
+/* replaces AnchorAssigner.create_mask (anchor_assigner.py:322-335; box_np_ops.py:168-257).
+ * mask u8[A] (0/1). */
+int pp_anchor_mask(pp_ctx* ctx, const int32_t* coors, const int32_t* num_pillars, uint8_t* mask, void* stream);
+
+/* replaces PointNet.forward (pointpillars8_shared.py:30-60). feat f32[max_voxels,64], rows < *num_pillars written. */
+int pp_pfn(pp_ctx* ctx, const float* voxels, const int32_t* coors, const int32_t* npts,
+           const int32_t* num_pillars, float* feat, void* stream);
+
+/* replaces PointPillarsScatter.forward (pointpillars8_shared.py:76-111; CUDA scatter of
+ * pointpillars8_trt.py:176-193). canvas f32[64,gx,gy], fully written (zero fill + scatter). */
+int pp_scatter(pp_ctx* ctx, const float* feat, const int32_t* coors, const int32_t* num_pillars,
+               float* canvas, void* stream);
+
+/* replaces RPN.forward (pointpillars8_shared.py:173-181). canvas f32[64,gx,gy] -> rpn_out f32[320,gx/2,gy/2]. */
+int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, void* stream);
+
+/* replaces SharedHead.forward (pointpillars8_shared.py:323-343). rpn_out f32[320,H,W] ->
+ * cls f32[A] , box f32[A,7], dir f32[A,2], ordered (anchor type, x, y). */
+int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box, float* dir, void* stream);
+
+/* replaces Inference.infer_gpu (inference.py:26-138). det f32[num_classes*nms_post_max, 9] rows
+ * (x,y,z,l,w,h,r,score,class) grouped by class in class order, det_count i32[1+num_classes]
+ * (total, then per class). nms_mode 0 = axis-aligned "+1" NMS (nms.py), 1 = rotated (eval/iou.py). */
+int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
+                   float* det, int32_t* det_count, int nms_mode, void* stream);
+
+/* Fused frame: voxelise -> mask -> PFN -> (sparse) BEV -> backbone -> head -> post-process, no host sync. */
+int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream);
+
+/* Stateless box ops (replace framework/box_torch_ops.py:18-77 and framework/nms.py:6-40,
+ * eval/iou.py:438-473). */
+int pp_box_decode(const float* enc, const float* anchors, float* out, int64_t n, void* stream);
+int pp_corners2d(const float* centers, const float* dims, const float* angles /* may be NULL */, float* corners /*[n,4,2]*/,
+                 int64_t n, void* stream);
+int pp_standup2d(const float* corners /*[n,4,2]*/, float* boxes /*[n,4]*/, int64_t n, void* stream);
+/* dets f32[n,stride] (stride 5: x1,y1,x2,y2,score; 6: cx,cy,dx,dy,angle,score); keep i32[n], nkeep i32[1].
+ * Sorts by score (desc, ties by lower index), builds the 64x64 bitmask tiles, greedy sweep on device. */
+int pp_nms(const float* dets, int n, int stride, float thresh, int32_t* keep, int32_t* nkeep, int rotate, void* stream);
+int pp_rotated_iou(const float* boxes_a /*[n,5]*/, const float* boxes_b /*[m,5]*/, float* iou /*[n,m]*/, int n, int m, void* stream);
+
+/* Measurement hooks for bench.py: between begin and end every launch of the dominant kernel
+ * (conv3x3 stride 1 on the level-0 map, 3 launches per frame) is bracketed by hipEvents on the
+ * launch stream.  pp_profile_end synchronises the events and reports the average duration (ms),
+ * the number of launches seen and the algorithmic FLOPs of one launch (2*H*W*Cin*Cout*9). */
+int pp_profile_begin(pp_ctx* ctx);
+int pp_profile_end(pp_ctx* ctx, double* avg_ms_h, int32_t* launches_h, double* flops_per_launch_h);
+int pp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H */
