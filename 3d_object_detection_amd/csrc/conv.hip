@@ -24,8 +24,10 @@
 // * ConvTranspose(k = s, stride = s) is a 1x1 conv onto Cout*s*s virtual channels whose epilogue
 //   pixel-shuffles (float2 / float4 stores); the three upsampled maps land in one [320,H,W]
 //   buffer, so the concat is free and the head normalises + ReLUs them in its prologue.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "pp_common.h"
 
@@ -62,8 +64,6 @@ struct ConvP {
     int n_rows;       // 90
 };
 
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
 struct ConvCfg {
     static constexpr int TH = 16 / TW;
@@ -71,41 +71,52 @@ struct ConvCfg {
     static constexpr int BTY = TILES / BTX;
     static constexpr int PW = BTX * TW, PH = BTY * TH;
     static constexpr int IW = (PW - 1) * STRIDE + KS, IH = (PH - 1) * STRIDE + KS;
+    static constexpr int HALF = (IW + 1) / 2; // stride 2: even columns first, odd columns after (de-interleaved)
     static constexpr int iwp()
     {
-        if (TW == 16) return IW;
         int v = IW;
-        while ((STRIDE * v) % 32 != TW) ++v; // rows of an N-tile land on disjoint bank groups
+        if (TW == 16) return v;
+        while ((STRIDE * v) % 32 != TW) ++v; // the TH rows of an N-tile land on disjoint bank groups
         return v;
     }
     static constexpr int IWP = iwp();
     static constexpr int cs()
     {
         int v = IH * IWP;
-        while (v % 32 != 16) ++v; // channel c+1 is 16 banks away from channel c
+        while (v % 32 != 16) ++v; // channel c+1 (lanes 16-31 / 48-63) is 16 banks away from channel c
         return v;
     }
     static constexpr int CS = cs();
     static constexpr int BM = WM * MT * 16;
     static constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
     static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int NPOS = IH * IW;                          // patch positions per channel
+    static constexpr int PR = (NPOS + THREADS - 1) / THREADS;     // positions per thread
+    static constexpr int W4 = KS * KS * KC * BMP / 4;             // float4 per weight chunk image
+    static constexpr int WR = (W4 + THREADS - 1) / THREADS;
     static constexpr int LDS_IN = KC * CS;
     static constexpr int LDS_W = KS * KS * KC * BMP;
-    static constexpr int LDS_FLOATS = LDS_IN + LDS_W + 2 * 320 + 2 * WN * BM;
+    static constexpr int LDS_FLOATS = 2 * (LDS_IN + LDS_W) + 2 * 320 + 2 * WN * BM;
     static_assert(TILES % BTX == 0, "tiles must form a rectangle");
     static_assert(KC % 4 == 0, "KC multiple of the MFMA K");
+    static_assert((KS * KS * KC * BMP) % 4 == 0 && LDS_IN % 4 == 0, "float4 staging");
 };
 
+// Software pipeline per channel chunk (one barrier per chunk):
+//   global loads of chunk c+1 -> registers   (in flight during the MFMAs)
+//   MFMAs of chunk c from LDS buffer c&1
+//   registers -> LDS buffer (c+1)&1 (normalise + ReLU + zero padding applied here)
+//   barrier
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 {
     using C = ConvCfg<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* il = smem;                // [KC][CS]
-    float* wl = il + C::LDS_IN;      // [KS*KS][KC][BMP]
-    float* scl = wl + C::LDS_W;      // [320] scale
-    float* shl = scl + 320;          // [320] shift
-    float* red = shl + 320;          // [WN][BM][2]
+    float* il = smem;                          // [2][KC][CS]
+    float* wl = il + 2 * C::LDS_IN;            // [2][KS*KS][KC][BMP]
+    float* scl = wl + 2 * C::LDS_W;            // [320] scale
+    float* shl = scl + 320;                    // [320] shift
+    float* red = shl + 320;                    // [WN][BM][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,6 +153,23 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         }
     }
 
+    // ---- per-thread staging map: position -> (global offset in a channel plane, LDS offset) ----
+    // Loads are UNCONDITIONAL (out-of-image positions read offset 0 of the plane and are zeroed when
+    // written to LDS): a per-element "load or 0" select makes hipcc branch around every load.
+    int goff[C::PR], loff[C::PR];
+    unsigned vmask = 0u;
+#pragma unroll
+    for (int r = 0; r < C::PR; ++r) {
+        const int pos = tid + r * C::THREADS;
+        const int iy = pos / C::IW, ix = pos - iy * C::IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool inb = pos < C::NPOS && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+        goff[r] = inb ? gy * p.Win + gx : 0;
+        vmask |= (inb ? 1u : 0u) << r;
+        const int col = (STRIDE == 2) ? ((ix & 1) * C::HALF + (ix >> 1)) : ix;
+        loff[r] = pos < C::NPOS ? iy * C::IWP + col : -1;
+    }
+
     // lane's pixel base inside the LDS patch for each of its N-tiles
     int toff[NT];
     int opx[NT], opy[NT];
@@ -152,7 +180,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         const int px = tx * TW + (m % TW), py = ty * C::TH + (m / TW);
         opx[nt] = ox0 + px;
         opy[nt] = oy0 + py;
-        toff[nt] = (py * STRIDE) * C::IWP + px * STRIDE + kq * C::CS;
+        toff[nt] = (py * STRIDE) * C::IWP + px + kq * C::CS; // stride 2: px indexes the even-column plane
     }
     const int aoff = kq * C::BMP + wm * MT * 16 + m;
 
@@ -164,45 +192,65 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
     const size_t in_plane = (size_t)p.Hin * p.Win;
     const int nchunk = p.Cin / KC;
-    const float* wsrc = p.w + (size_t)blockIdx.y * nchunk * (KS * KS * KC * C::BM);
+    const float4* wsrc = reinterpret_cast<const float4*>(p.w) + (size_t)blockIdx.y * nchunk * C::W4;
+
+    float xv[C::PR][KC];
+    f32x4 wv[C::WR];
+    const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(wsrc);
+
+#define PP_LOAD_CHUNK(CH)                                                                        \
+    {                                                                                            \
+        const float* base_ = p.in + (size_t)((CH) * KC) * in_plane;                              \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
+            _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
+        const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
+        _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
+            const int e_ = tid + r * C::THREADS;                                                 \
+            wv[r] = g_[e_ < C::W4 ? e_ : C::W4 - 1];                                             \
+        }                                                                                        \
+    }
+#define PP_STORE_CHUNK(CH, BUF)                                                                  \
+    {                                                                                            \
+        float* ib_ = il + (BUF) * C::LDS_IN;                                                     \
+        const int c0_ = (CH) * KC;                                                               \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                      \
+            if (loff[r] >= 0) {                                                                  \
+                const bool inb_ = (vmask >> r) & 1u;                                             \
+                _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                 \
+                    float v_ = xv[r][c];                                                         \
+                    if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, scl[c0_ + c], shl[c0_ + c]), 0.f); \
+                    ib_[c * C::CS + loff[r]] = inb_ ? v_ : 0.f;                                  \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+        f32x4* wb_ = reinterpret_cast<f32x4*>(wl + (BUF) * C::LDS_W);                            \
+        _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
+            const int e_ = tid + r * C::THREADS;                                                 \
+            if (e_ < C::W4) wb_[e_] = wv[r];                                                     \
+        }                                                                                        \
+    }
+
+    PP_LOAD_CHUNK(0)
+    __syncthreads(); // scl/shl visible
+    PP_STORE_CHUNK(0, 0)
+    __syncthreads();
 
     for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads(); // previous chunk fully consumed (and scl/shl visible on the first pass)
-        // ---- stage the input patch: zero padding + normalise + ReLU on the fly ----
-        const int c0 = ch * KC;
-        for (int idx = tid; idx < KC * C::IH * C::IW; idx += C::THREADS) {
-            const int c = idx / (C::IH * C::IW);
-            const int r = idx - c * (C::IH * C::IW);
-            const int iy = r / C::IW, ix = r - iy * C::IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            float v = 0.f;
-            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) {
-                v = p.in[(size_t)(c0 + c) * in_plane + (size_t)gy * p.Win + gx];
-                if (p.pre != PRE_RAW) v = fmaxf(fmaf(v, scl[c0 + c], shl[c0 + c]), 0.f);
-            }
-            il[c * C::CS + iy * C::IWP + ix] = v;
-        }
-        // ---- stage the weight slab [tap][kc][BM] -> padded rows ----
-        {
-            const float4* g = reinterpret_cast<const float4*>(wsrc + (size_t)ch * (KS * KS * KC * C::BM));
-            constexpr int N4 = KS * KS * KC * C::BM / 4;
-            for (int e = tid; e < N4; e += C::THREADS) {
-                const int row = (e * 4) / C::BM, col = (e * 4) % C::BM;
-                *reinterpret_cast<float4*>(&wl[row * C::BMP + col]) = g[e];
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over taps x channel quads ----
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) PP_LOAD_CHUNK(ch + 1)
+        const float* ib = il + buf * C::LDS_IN;
+        const float* wb = wl + buf * C::LDS_W;
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
+            const int tapoff = ky * C::IWP + ((STRIDE == 2) ? ((kx & 1) * C::HALF + (kx >> 1)) : kx);
 #pragma unroll
             for (int c4 = 0; c4 < KC / 4; ++c4) {
                 float a[MT], b[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = wl[(tap * KC + c4 * 4) * C::BMP + aoff + i * 16];
+                for (int i = 0; i < MT; ++i) a[i] = wb[(tap * KC + c4 * 4) * C::BMP + aoff + i * 16];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = il[toff[j] + c4 * 4 * C::CS + ky * C::IWP + kx];
+                for (int j = 0; j < NT; ++j) b[j] = ib[toff[j] + c4 * 4 * C::CS + tapoff];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -210,6 +258,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (ch + 1 < nchunk) PP_STORE_CHUNK(ch + 1, buf ^ 1)
+        __syncthreads();
     }
 
     // ---- epilogue ----
@@ -249,8 +299,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
                 for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
             } else if (EPI == EPI_UP4) { // rows (co*16 + dy*4 + dx) -> out[co][4y+dy][4x+dx]
                 const int co = row0 >> 4, dy = (row0 >> 2) & 3;
-                const size_t W4 = (size_t)p.Wout * 4;
-                float* o = p.out + (size_t)co * out_plane * 16 + (size_t)(4 * opy[j] + dy) * W4 + 4 * opx[j];
+                const size_t W4o = (size_t)p.Wout * 4;
+                float* o = p.out + (size_t)co * out_plane * 16 + (size_t)(4 * opy[j] + dy) * W4o + 4 * opx[j];
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
@@ -276,7 +326,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
     if (EPI != EPI_HEAD && p.stat_acc) {
         // reduce over the 16 pixel lanes, then over the WN waves through LDS, then fp64 atomics
-        __syncthreads(); // `red` aliases nothing, but all waves must be past the MFMA loop's LDS reads
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -379,8 +428,9 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 struct Variant { // one compiled tiling of conv_mfma
     void (*kern)(const ConvP);
-    int bm, pw, ph, kc, threads;
+    int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
     size_t lds;
+    char name[48];
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -389,8 +439,10 @@ Variant make_variant()
     using C = ConvCfg<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
     Variant v;
     v.kern = conv_mfma<KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI>;
-    v.bm = C::BM; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
+    v.bm = C::BM; v.bmp = C::BMP; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
+    v.waves = WM * WN; v.pairs = MT * NT;
     v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    snprintf(v.name, sizeof(v.name), "k%ds%d tw%d w%dx%d t%dx%d bx%d kc%d e%d", KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI);
     return v;
 }
 
@@ -428,25 +480,78 @@ struct pp_net {
 
 const int kC[3] = {64, 128, 256};
 
-Variant pick_variant(int kind, int stride, int up, int level, int H, int W)
+// Tiling menu.  The 16-pixel N-tile is TW x (16/TW); a workgroup covers BTX x BTY tiles.  The maps of
+// eight_20cm are 400/200/100 = 16*25 / 8*25 / 4*25, so NT=5 shapes tile them exactly; the 4x4 / 2x2 shapes
+// are the general fallback (edge tiles masked).  Which entry runs a layer is MEASURED on the device at
+// pp_commit_weights (autotune below); the cost model only breaks ties / serves PP_AUTOTUNE=0.
+template <int KS, int STRIDE, int KC, int EPI>
+void conv_menu(std::vector<Variant>& m)
 {
-    (void)H; (void)W;
-    if (kind == 2) return make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>();
-    if (kind == 1) {
-        if (up == 1) return make_variant<1, 1, 16, 1, 4, 4, 4, 1, 16, EPI_PLAIN>();
-        if (up == 2) return make_variant<1, 1, 8, 2, 2, 4, 2, 2, 16, EPI_UP2>();
-        return make_variant<1, 1, 4, 2, 2, 4, 2, 2, 16, EPI_UP4>();
+    constexpr int KH = (KC >= 8) ? KC / 2 : KC;
+    //                            TW WM WN MT NT BTX
+    m.push_back(make_variant<KS, STRIDE, 16, 1, 4, 4, 5, 1, KC, EPI>()); // 16x20 px, 64 rows
+    m.push_back(make_variant<KS, STRIDE, 16, 1, 4, 4, 5, 1, KH, EPI>());
+    m.push_back(make_variant<KS, STRIDE, 16, 1, 4, 4, 4, 1, KC, EPI>()); // 16x16 px, 64 rows
+    m.push_back(make_variant<KS, STRIDE, 16, 2, 2, 2, 5, 1, KH, EPI>()); // 16x10 px, 64 rows, light waves
+    m.push_back(make_variant<KS, STRIDE, 16, 1, 4, 2, 5, 1, KC, EPI>()); // 16x20 px, 32 rows
+    m.push_back(make_variant<KS, STRIDE, 8, 2, 2, 4, 5, 5, KC, EPI>());  // 40x4 px, 128 rows
+    m.push_back(make_variant<KS, STRIDE, 8, 2, 2, 4, 5, 5, KH, EPI>());
+    m.push_back(make_variant<KS, STRIDE, 8, 4, 1, 2, 5, 5, KC, EPI>());  // 40x2 px, 128 rows, light waves
+    m.push_back(make_variant<KS, STRIDE, 8, 2, 2, 4, 2, 2, KC, EPI>());  // 16x4 px, 128 rows
+    m.push_back(make_variant<KS, STRIDE, 8, 1, 4, 4, 4, 2, KC, EPI>());  // 16x16 px, 64 rows
+    m.push_back(make_variant<KS, STRIDE, 4, 4, 1, 2, 5, 5, KC, EPI>());  // 20x4 px, 128 rows
+    m.push_back(make_variant<KS, STRIDE, 4, 4, 1, 2, 5, 5, KH, EPI>());
+    m.push_back(make_variant<KS, STRIDE, 4, 8, 1, 1, 5, 5, KC, EPI>());  // 20x4 px, 128 rows, 8 light waves
+    m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 4, 5, 5, KC, EPI>());  // 20x8 px, 128 rows
+    m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 4, 2, 2, KC, EPI>());  // 8x8 px, 128 rows
+    m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
+}
+
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu)
+{
+    if (kind == 2) {
+        menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 5, 1, 16, EPI_HEAD>());
+        menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
+        menu.push_back(make_variant<1, 1, 16, 2, 2, 3, 5, 1, 16, EPI_HEAD>());
+        menu.push_back(make_variant<1, 1, 16, 2, 4, 3, 5, 1, 32, EPI_HEAD>());
+        menu.push_back(make_variant<1, 1, 8, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
+        menu.push_back(make_variant<1, 1, 8, 2, 2, 3, 4, 2, 16, EPI_HEAD>());
+    } else if (kind == 1) {
+        if (up == 1) conv_menu<1, 1, 16, EPI_PLAIN>(menu);
+        else if (up == 2) conv_menu<1, 1, 16, EPI_UP2>(menu);
+        else conv_menu<1, 1, 16, EPI_UP4>(menu);
+    } else if (stride == 2) {
+        conv_menu<3, 2, 8, EPI_PLAIN>(menu);
+    } else {
+        conv_menu<3, 1, 8, EPI_PLAIN>(menu);
     }
-    if (level == 0) {
-        if (stride == 2) return make_variant<3, 2, 16, 1, 4, 4, 4, 1, 8, EPI_PLAIN>();
-        return make_variant<3, 1, 16, 1, 4, 4, 4, 1, 8, EPI_PLAIN>();
+}
+
+// cost model: wavefronts are dealt to 1024 SIMDs; a SIMD's time ~ (its wave count) x (tile pairs per wave).
+double model_cost(const Variant& v, int rows, int Hout, int Wout)
+{
+    const double blocks = (double)pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph) * pp_div_up(rows, v.bm);
+    const double waves = blocks * v.waves;
+    double cost = std::ceil(waves / 1024.0) * v.pairs;
+    if (waves < 1536.0) cost *= 1.15;          // a lone wave per SIMD cannot hide its own staging
+    cost *= 1.0 + 0.02 * (20.0 / v.pairs);     // smaller wave tiles re-read operands more often
+    return cost;
+}
+
+bool variant_ok(const Variant& v, int rows) { return v.bm <= ((rows + 63) / 64) * 64; }
+
+Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
+{
+    std::vector<Variant> menu;
+    layer_menu(kind, stride, up, menu);
+    double best = 1e30;
+    Variant bv = menu[0];
+    for (const Variant& v : menu) {
+        if (!variant_ok(v, rows)) continue;
+        const double c = model_cost(v, rows, Hout, Wout);
+        if (c < best) { best = c; bv = v; }
     }
-    if (level == 1) {
-        if (stride == 2) return make_variant<3, 2, 8, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
-        return make_variant<3, 1, 8, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
-    }
-    if (stride == 2) return make_variant<3, 2, 4, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
-    return make_variant<3, 1, 4, 2, 2, 4, 2, 2, 8, EPI_PLAIN>();
+    return bv;
 }
 
 int pack_layer(pp_ctx* ctx, Layer& L)
@@ -488,7 +593,7 @@ int pack_layer(pp_ctx* ctx, Layer& L)
     }
     L.rows = rows;
     const int nblk = pp_div_up(rows, v.bm), nchunk = L.cin / v.kc;
-    std::vector<float> pk((size_t)nblk * nchunk * taps * v.kc * v.bm, 0.f);
+    std::vector<float> pk((size_t)nblk * nchunk * taps * v.kc * v.bmp, 0.f); // LDS image incl. row padding
     for (int b = 0; b < nblk; ++b)
         for (int ch = 0; ch < nchunk; ++ch)
             for (int t = 0; t < taps; ++t)
@@ -496,7 +601,7 @@ int pack_layer(pp_ctx* ctx, Layer& L)
                     for (int mm = 0; mm < v.bm; ++mm) {
                         const int row = b * v.bm + mm;
                         if (row >= rows) continue;
-                        pk[((((size_t)b * nchunk + ch) * taps + t) * v.kc + k) * v.bm + mm] =
+                        pk[((((size_t)b * nchunk + ch) * taps + t) * v.kc + k) * v.bmp + mm] =
                             rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps + t];
                     }
     if (L.w) (void)hipFree(L.w);
@@ -543,6 +648,75 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     return 0;
 }
 
+
+__global__ void __launch_bounds__(256) fill_pattern(float* __restrict__ x, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = (float)(h & 0xFFFF) * (1.0f / 65536.0f); // [0,1): random-looking, not zeros (zeros raise the clock)
+    }
+}
+
+std::map<std::string, std::string>& tune_cache()
+{
+    static std::map<std::string, std::string> c; // layer signature -> variant name, per process
+    return c;
+}
+
+// Measure every admissible tiling of one layer on the device (1 warm-up + 3 timed launches with
+// hipEvents) and keep the fastest.  Weights are really packed for each candidate, the prologue /
+// statistics epilogue run as in production.
+int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose)
+{
+    pp_net* net = (pp_net*)ctx->net;
+    char sig[160];
+    snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind);
+    std::vector<Variant> menu;
+    layer_menu(L.kind, L.stride, L.up, menu);
+    const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
+    auto hit = tune_cache().find(sig);
+    if (hit != tune_cache().end()) {
+        for (const Variant& v : menu)
+            if (hit->second == v.name) { L.var = v; return 0; }
+    }
+    hipEvent_t e0, e1;
+    PP_HIP(hipEventCreate(&e0));
+    PP_HIP(hipEventCreate(&e1));
+    NormRef pre;
+    if (L.kind == 2 || (L.kind == 0 && L.stride == 1)) { pre.mode = PRE_AFFINE; pre.scale = net->ones; pre.shift = net->zeros; }
+    double* st = (ctx->cfg.norm_kind == 0 && L.kind != 2) ? net->stats + (size_t)23 * NREP * 320 * 2 : nullptr;
+    const int stC = (L.kind == 1) ? 320 : L.cout;
+    double best = 1e30;
+    Variant bv = L.var;
+    for (const Variant& v : menu) {
+        if (!variant_ok(v, rows)) continue;
+        if (v.lds > 160 * 1024) continue;
+        L.var = v;
+        PP_HIP(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        int rc = pack_layer(ctx, L);
+        if (rc) return rc;
+        float ms = 0.f;
+        for (int it = 0; it < 4; ++it) {
+            if (it == 1) PP_HIP(hipEventRecord(e0, 0));
+            rc = launch_conv(ctx, L, tin, Hin, Win, (L.kind == 2) ? ctx->f_cls : tout, nullptr, pre, st, stC, Hout, Wout, 0, ctx->f_box, ctx->f_dir);
+            if (rc) return rc;
+        }
+        PP_HIP(hipEventRecord(e1, 0));
+        PP_HIP(hipEventSynchronize(e1));
+        PP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 3.f;
+        if (verbose) fprintf(stderr, "[pp autotune] %-28s %-34s %8.1f us\n", sig, v.name, ms * 1e3);
+        if (ms < best) { best = ms; bv = v; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    L.var = bv;
+    tune_cache()[sig] = bv.name;
+    if (verbose) fprintf(stderr, "[pp autotune] %-28s -> %s (%.1f us)\n", sig, bv.name, best * 1e3);
+    return 0;
+}
+
 } // namespace
 
 int pp_net_create(pp_ctx* ctx)
@@ -573,22 +747,22 @@ int pp_net_create(pp_ctx* ctx)
         const int nunits = (b == 0) ? 2 : 3;
         char key[128];
         snprintf(key, sizeof(key), "rpn.block%d.0.weight", b + 1);
-        net->layers.push_back(Layer{key, 0, cin, c, 2, 1, b, pick_variant(0, 2, 1, b, H, W)});
+        net->layers.push_back(Layer{key, 0, cin, c, 2, 1, b, pick_variant(0, 2, 1, c, H >> b, W >> b)});
         for (int u = 0; u < nunits; ++u) {
             const int nl = (b == 0) ? (u == 0 ? 1 : 0) : nres[u];
             snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.2.weight", b + 1, 3 + u);
-            net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, b, H, W)});
+            net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, c, H >> b, W >> b)});
             if (nl == 1) {
                 snprintf(key, sizeof(key), "rpn.block%d.%d.conv_block.5.weight", b + 1, 3 + u);
-                net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, b, H, W)});
+                net->layers.push_back(Layer{key, 0, c, c, 1, 1, b, pick_variant(0, 1, 1, c, H >> b, W >> b)});
             }
         }
         const int up = 1 << b;
         snprintf(key, sizeof(key), "rpn.deconv%d.0.weight", b + 1);
-        net->layers.push_back(Layer{key, 1, c, (b == 0) ? 64 : 128, 1, up, b, pick_variant(1, 1, up, b, H, W)});
+        net->layers.push_back(Layer{key, 1, c, (b == 0) ? 64 : 128, 1, up, b, pick_variant(1, 1, up, ((b == 0) ? 64 : 128) * up * up, H >> b, W >> b)});
         cin = c;
     }
-    net->layers.push_back(Layer{"heads", 2, 320, 90, 1, 1, 0, pick_variant(2, 1, 1, 0, H, W)});
+    net->layers.push_back(Layer{"heads", 2, 320, 90, 1, 1, 0, pick_variant(2, 1, 1, 96, H, W)});
     for (Layer& L : net->layers)
         PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
     return 0;
@@ -640,10 +814,6 @@ static inline int site_block(int b, int k) { return 8 * b + k; }
 int pp_net_commit(pp_ctx* ctx)
 {
     pp_net* net = (pp_net*)ctx->net;
-    for (Layer& L : net->layers) {
-        int rc = pack_layer(ctx, L);
-        if (rc) return rc;
-    }
     float hb[96] = {0};
     const char* names[3] = {"heads.conv_cls.bias", "heads.conv_box.bias", "heads.conv_dir.bias"};
     const int cnt[3] = {9, 63, 18};
@@ -656,6 +826,34 @@ int pp_net_commit(pp_ctx* ctx)
         r0 += cnt[h];
     }
     PP_HIP(hipMemcpy(net->head_bias, hb, sizeof(hb), hipMemcpyHostToDevice));
+    {
+        const char* at = getenv("PP_AUTOTUNE");
+        const char* vb = getenv("PP_VERBOSE");
+        const bool tune = !(at && at[0] == '0');
+        const bool verbose = vb && vb[0] != '0';
+        const int H = ctx->H, W = ctx->W;
+        float *tin = nullptr, *tout = nullptr;
+        const bool can_tune = tune && (H % 4 == 0) && (W % 4 == 0);
+        if (can_tune) {
+            const size_t nin = std::max((size_t)64 * ctx->gx * ctx->gy, (size_t)320 * H * W);
+            PP_HIP(hipMalloc((void**)&tin, nin * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&tout, (size_t)320 * H * W * sizeof(float)));
+            hipLaunchKernelGGL(fill_pattern, dim3(2048), dim3(256), 0, 0, tin, nin);
+        }
+        for (Layer& L : net->layers) {
+            int rc = 0;
+            if (can_tune) {
+                const int h = H >> L.level, w = W >> L.level;
+                const int hin = (L.kind == 0 && L.stride == 2) ? h * 2 : h, win = (L.kind == 0 && L.stride == 2) ? w * 2 : w;
+                rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose);
+                if (rc) { (void)hipFree(tin); (void)hipFree(tout); return rc; }
+            }
+            PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
+            rc = pack_layer(ctx, L);
+            if (rc) return rc;
+        }
+        if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); }
+    }
     if (ctx->cfg.norm_kind == 1) {
         for (int b = 0; b < 3; ++b) {
             char key[128];
