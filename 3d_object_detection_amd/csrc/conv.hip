@@ -25,6 +25,7 @@
 //   pixel-shuffles (float2 / float4 stores); the three upsampled maps land in one [320,H,W]
 //   buffer, so the concat is free and the head normalises + ReLUs them in its prologue.
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,16 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NREP = 8; // replicated statistics accumulators (spreads atomic contention)
+
+// compile-time for: f(integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void pp_steps(F&& f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        pp_steps<B + 1, E>(f);
+    }
+}
 
 enum { EPI_PLAIN = 0, EPI_UP2 = 1, EPI_UP4 = 2, EPI_HEAD = 3 };
 enum { PRE_RAW = 0, PRE_STATS = 1, PRE_AFFINE = 2 };
@@ -62,6 +73,7 @@ struct ConvP {
     float* out_dir;
     int n_cls, n_box; // 9, 63 (dir = rest up to n_rows)
     int n_rows;       // 90
+    int dbg;          // diagnostics only (PP_CONV_DBG): 1 = skip staging after chunk 0, 4 = skip epilogue
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -237,32 +249,42 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunk) PP_LOAD_CHUNK(ch + 1)
+        if (ch + 1 < nchunk && !(p.dbg & 1)) PP_LOAD_CHUNK(ch + 1)
         const float* ib = il + buf * C::LDS_IN;
         const float* wb = wl + buf * C::LDS_W;
+        // Operand reads run ONE STEP AHEAD of the MFMAs that consume them (two register sets, order
+        // pinned with sched_barrier): left alone, hipcc issues each step's ds_reads right before its
+        // MFMAs and every step eats the LDS latency.
+        constexpr int NS = KS * KS * (KC / 4);
+        float a[2][MT], b[2][NT];
+#define PP_LOAD_OPS(S, SET)                                                                          \
+    {                                                                                                \
+        constexpr int tap_ = (S) / (KC / 4), c4_ = (S) % (KC / 4);                                   \
+        constexpr int ky_ = tap_ / KS, kx_ = tap_ % KS;                                              \
+        constexpr int tapoff_ = ky_ * C::IWP + ((STRIDE == 2) ? ((kx_ & 1) * C::HALF + (kx_ >> 1)) : kx_); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[SET][i] = wb[(tap_ * KC + c4_ * 4) * C::BMP + aoff + i * 16]; \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) b[SET][j] = ib[toff[j] + c4_ * 4 * C::CS + tapoff_]; \
+    }
+        PP_LOAD_OPS(0, 0)
+        pp_steps<0, NS>([&](auto S) {
+            constexpr int s_ = decltype(S)::value;
+            constexpr int cur = s_ & 1;
+            if constexpr (s_ + 1 < NS) PP_LOAD_OPS(s_ + 1, cur ^ 1)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
-            const int tapoff = ky * C::IWP + ((STRIDE == 2) ? ((kx & 1) * C::HALF + (kx >> 1)) : kx);
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int c4 = 0; c4 < KC / 4; ++c4) {
-                float a[MT], b[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = wb[(tap * KC + c4 * 4) * C::BMP + aoff + i * 16];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = ib[toff[j] + c4 * 4 * C::CS + tapoff];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (ch + 1 < nchunk) PP_STORE_CHUNK(ch + 1, buf ^ 1)
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#undef PP_LOAD_OPS
+        if (ch + 1 < nchunk && !(p.dbg & 1)) PP_STORE_CHUNK(ch + 1, buf ^ 1)
         __syncthreads();
     }
 
     // ---- epilogue ----
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; return; }
     const size_t out_plane = (size_t)p.Hout * p.Wout;
     float ssum[MT][4], ssq[MT][4];
 #pragma unroll
@@ -625,6 +647,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.stat_acc = stat_acc; p.stat_C = stat_C;
     p.bias = net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
     p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
+    { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
     const Variant& v = L.var;
     dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm));
     const bool tag = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;

@@ -1,0 +1,108 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/pp_hip.h declares,
+the host-side mirrors (geometry snap, anchor tables) match the goldens taken from the reference,
+and the product path refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, load_pkg
+
+HEADER = os.path.join(ROOT, "include", "pp_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib_mod = load_pkg("_lib")
+    lib = lib_mod.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libpp_hip.so does not export {s}"
+        assert s in lib_mod.PROTOTYPES, f"_lib.PROTOTYPES lacks {s}"
+    assert set(lib_mod.PROTOTYPES) == set(syms)
+    assert lib.pp_version() >= 1
+
+
+def test_config_struct_layout_matches_header():
+    lib_mod = load_pkg("_lib")
+    c = lib_mod.PPConfig
+    # offsets as laid out by a C compiler for the struct in pp_hip.h (natural alignment)
+    assert c.voxel_size.offset == 0 and c.offset.offset == 12 and c.grid_size.offset == 24
+    assert c.max_voxels.offset == 36 and c.class_begin.offset == 60 and c.class_end.offset == 92
+    assert c.center_limit.offset == 128 and c.norm_kind.offset == 176
+    assert ctypes.sizeof(c) == 200
+
+
+def test_no_gpu_no_fallback(synth):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    eng = load_pkg("engine")
+    with pytest.raises(RuntimeError):
+        eng.Engine(synth.load_config("eight_20cm"))
+    lib = load_pkg("_lib").load()
+    cfg = load_pkg("_lib").PPConfig()
+    assert not lib.pp_create(0, ctypes.byref(cfg))  # invalid config / no device -> NULL, message available
+    assert lib.pp_last_error(None)
+
+
+@pytest.mark.parametrize("name", ["eight_20cm", "ntusl_10cm", "nuscene"])
+def test_snap_geometry(name, synth):
+    eng = load_pkg("engine")
+    g = golden(f"setup_{name}")
+    vs, off, grid, rd, dr = eng.snap_geometry(synth.load_config(name))
+    assert np.array_equal(vs, g["voxel_size"]) and np.array_equal(off, g["offset"]) and np.array_equal(grid, g["grid_size"])
+    assert np.array_equal(rd, g["range_diff"]) and np.array_equal(dr, g["detection_range"])
+    assert off.dtype == np.float32 and grid.dtype == np.int32
+
+
+def test_anchor_tables_match_reference(synth):
+    import hashlib
+    eng = load_pkg("engine")
+    g = golden("anchors_eight_20cm")
+    vs, off, grid, rd, _ = eng.snap_geometry(synth.load_config("eight_20cm"))
+    anchors, bv, rects, masks = eng.build_anchor_tables(off, rd, grid, vs)
+
+    def sha(a):
+        a = np.ascontiguousarray(a)
+        h = hashlib.sha256()
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+        return h.hexdigest()
+
+    assert sha(anchors) == str(g["anchors_sha"]) and sha(rects) == str(g["coors_sha"])
+    assert np.array_equal(bv[g["rows"]], g["bv_rows"])
+    assert list(masks.keys()) == [str(x) for x in g["class_names"]]
+    assert np.array_equal(np.array(list(masks.values())), g["class_ranges"])
+
+
+def test_voxel_generator_mutates_config_and_pickles(synth):
+    pkg = load_pkg()
+    pkg.install()
+    from framework.voxel_generator import VoxelGenerator
+    cfg = synth.load_config("eight_20cm")
+    vg = VoxelGenerator(cfg)
+    for k in ("detection_range", "detection_offset", "detection_range_diff", "grid_size"):
+        assert k in cfg
+    assert list(cfg["grid_size"]) == [800, 800, 1]
+    vg2 = pickle.loads(pickle.dumps(vg))
+    assert np.array_equal(vg2.offset, vg.offset) and vg2.max_voxels == 16000
+
+
+def test_synthetic_cloud_shapes(synth):
+    for name, n in (("eight_20cm", 20000), ("ntusl_10cm", 60000), ("nuscene", 34000)):
+        p = synth.lidar_cloud(name, seed=3)
+        assert p.shape == (n, 4) and p.dtype == np.float32 and np.isfinite(p).all()
+    a, b = synth.lidar_cloud("eight_20cm", 5), synth.lidar_cloud("eight_20cm", 5)
+    assert np.array_equal(a, b)
+    sd = synth.seeded_state_dict(0)
+    assert len([k for k in sd]) == 30 and sd["rpn.deconv3.0.weight"].shape == (256, 128, 4, 4)

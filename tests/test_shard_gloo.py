@@ -1,0 +1,63 @@
+"""CPU: the N>1 frame-sharding path with world_size=2 over gloo (the GPU run uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_pkg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, out):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    shard = importlib.import_module("3d_object_detection_amd.shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.frames_for_rank(rank, world, n_frames)
+    rows = 6
+    det = torch.zeros((len(mine), rows, 9))
+    cnt = torch.zeros((len(mine), 4), dtype=torch.int32)
+    for j, f in enumerate(mine):  # fake per-frame detections: frame f has (f % rows) rows filled with f
+        k = f % rows
+        det[j, :k] = float(f)
+        cnt[j, 0] = k
+    t0 = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t0, op=dist.ReduceOp.MAX)  # the max-over-ranks timing of bench.py
+    dets, cnts = shard.gather_detections(det, cnt)
+    merged = shard.merge_in_frame_order(dets, cnts, n_frames)
+    ok = abs(float(t0) - 0.1 * world) < 1e-12
+    for f, (d, c) in enumerate(merged):
+        ok &= d.shape[0] == f % rows and bool((d == float(f)).all()) and int(c[0]) == f % rows
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_world2():
+    shard = load_pkg("shard")
+    assert shard.frames_for_rank(0, 2, 5) == [0, 2, 4] and shard.frames_for_rank(1, 2, 5) == [1, 3]
+    assert sorted(sum((shard.frames_for_rank(r, 8, 64) for r in range(8)), [])) == list(range(64))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 8, out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+def test_single_process_gather_is_identity():
+    shard = load_pkg("shard")
+    det, cnt = torch.ones((2, 3, 9)), torch.tensor([[3, 1, 1, 1], [2, 1, 1, 0]], dtype=torch.int32)
+    d, c = shard.gather_detections(det, cnt)
+    assert len(d) == 1 and d[0] is det and c[0] is cnt
