@@ -683,8 +683,37 @@ __global__ void __launch_bounds__(256) fill_pattern(float* __restrict__ x, size_
 
 std::map<std::string, std::string>& tune_cache()
 {
-    static std::map<std::string, std::string> c; // layer signature -> variant name, per process
+    // layer signature -> variant name, per process; PP_TUNE_CACHE=<file> persists it across processes
+    static std::map<std::string, std::string> c;
+    static bool loaded = false;
+    if (!loaded) {
+        loaded = true;
+        if (const char* path = getenv("PP_TUNE_CACHE")) {
+            if (FILE* f = fopen(path, "r")) {
+                char line[512];
+                while (fgets(line, sizeof(line), f)) {
+                    char* tab = strchr(line, '\t');
+                    if (!tab) continue;
+                    *tab = 0;
+                    char* val = tab + 1;
+                    val[strcspn(val, "\r\n")] = 0;
+                    c[line] = val;
+                }
+                fclose(f);
+            }
+        }
+    }
     return c;
+}
+
+void tune_cache_save()
+{
+    const char* path = getenv("PP_TUNE_CACHE");
+    if (!path) return;
+    if (FILE* f = fopen(path, "w")) {
+        for (auto& kv : tune_cache()) fprintf(f, "%s\t%s\n", kv.first.c_str(), kv.second.c_str());
+        fclose(f);
+    }
 }
 
 // Measure every admissible tiling of one layer on the device (1 warm-up + 3 timed launches with
@@ -875,7 +904,7 @@ int pp_net_commit(pp_ctx* ctx)
             rc = pack_layer(ctx, L);
             if (rc) return rc;
         }
-        if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); }
+        if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); tune_cache_save(); }
     }
     if (ctx->cfg.norm_kind == 1) {
         for (int b = 0; b < 3; ++b) {

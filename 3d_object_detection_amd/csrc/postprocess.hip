@@ -376,8 +376,11 @@ __device__ float rotated_iou_dev(const float* r1, const float* r2)
 // ---------------------------------------------------------------- Q5
 // grid (col tile, row tile, class); 64 threads; lane = COLUMN box, loop over the 64 row boxes;
 // the 64-bit ballot of the wave is the mask word of that row.
+// TRANSPOSED suppression mask: maskT[col][rt] holds, for column box `col`, the bits r of the row boxes
+// (rt*64 + r) that suppress it (IoU > thr and row < col).  One wave per (col tile, row tile); the lane owning a
+// column accumulates its own word while the row boxes are broadcast with readlane -- no ballot, no loads in the loop.
 __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, int nstride, const int32_t* __restrict__ nsel_p,
-                                               int nsel_stride, int K, int cb, float thr, int rotate, uint64_t* __restrict__ mask)
+                                               int nsel_stride, int K, int cb, float thr, int rotate, uint64_t* __restrict__ maskT)
 {
     const int c = blockIdx.z;
     const int n = nsel_p[c * nsel_stride];
@@ -386,34 +389,40 @@ __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, i
     const int lane = threadIdx.x;
     const int col = ct * 64 + lane;
     const float* base = nbox + (size_t)c * K * nstride;
-    float cbx[5] = {0, 0, 0, 0, 0};
+    float cbx[5] = {0, 0, 0, 0, 0}, rmine[5] = {0, 0, 0, 0, 0};
+    const int nq = rotate ? 5 : 4;
     if (col < n)
-        for (int q = 0; q < (rotate ? 5 : 4); ++q) cbx[q] = base[(size_t)col * nstride + q];
+        for (int q = 0; q < nq; ++q) cbx[q] = base[(size_t)col * nstride + q];
+    const int myrow = rt * 64 + lane;
+    if (myrow < n)
+        for (int q = 0; q < nq; ++q) rmine[q] = base[(size_t)myrow * nstride + q];
     const int rows = min(64, n - rt * 64);
+    uint64_t word = 0ull;
     for (int r = 0; r < rows; ++r) {
         const int row = rt * 64 + r;
         float rbx[5];
-        for (int q = 0; q < (rotate ? 5 : 4); ++q) rbx[q] = base[(size_t)row * nstride + q]; // wave-uniform
-        bool sup = false;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) rbx[q] = __shfl(rmine[q], r);
         if (col < n && col > row) {
             const float iou = rotate ? rotated_iou_dev(rbx, cbx) : iou_plus1(rbx, cbx);
-            sup = iou > thr;
+            if (iou > thr) word |= 1ull << r;
         }
-        const unsigned long long w = __ballot(sup);
-        if (lane == 0) mask[((size_t)c * K + row) * cb + ct] = w;
     }
+    if (col < n) maskT[((size_t)c * K + col) * cb + rt] = word;
 }
 
-// greedy sweep for one class by ONE wavefront; returns number kept (<= max_keep) in keep[]
-__device__ int nms_greedy_wave(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* __restrict__ keep)
+// Greedy sweep (nms_postprocess, nms.py:85-102) for one class by ONE wavefront on the transposed mask.
+// Lane j keeps the suppression word of tile j.  Per tile t: every lane loads its column's words for tile t
+// (diagonal) and the later tiles need only one load + one ballot each.  Returns #kept (<= max_keep).
+__device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int cb, int max_keep, int* __restrict__ keep)
 {
     const int lane = threadIdx.x & 63;
-    uint64_t remv = 0ull; // lane j (< cb) holds suppression word j
+    uint64_t remv = 0ull; // lane j: columns of tile j already suppressed
     int nk = 0;
     const int tiles = (n + 63) >> 6;
     for (int t = 0; t < tiles && nk < max_keep; ++t) {
         const int i = t * 64 + lane;
-        const uint64_t diag = (i < n) ? mask[(size_t)i * cb + t] : 0ull;
+        const uint64_t diag = (i < n) ? maskT[(size_t)i * cb + t] : 0ull; // rows of tile t suppressing column i
         const uint64_t rt = __shfl(remv, t);
         const int valid = min(64, n - t * 64);
         uint64_t alive = ~rt & (valid == 64 ? ~0ull : ((1ull << valid) - 1ull));
@@ -424,14 +433,23 @@ __device__ int nms_greedy_wave(const uint64_t* __restrict__ mask, int n, int cb,
             if (lane == 0) keep[nk] = t * 64 + b;
             ++nk;
             alive &= ~(1ull << b);
-            alive &= ~__shfl(diag, b);
+            alive &= ~__ballot((diag >> b) & 1ull); // columns of this tile suppressed by row b
         }
-        // fold the kept rows of this tile into the suppression words of later tiles
-        uint64_t k2 = kept;
-        while (k2) {
-            const int b = __ffsll((long long)k2) - 1;
-            k2 &= k2 - 1;
-            if (lane < cb && lane > t) remv |= mask[(size_t)(t * 64 + b) * cb + lane];
+        if (nk >= max_keep) break;
+        // fold: column (j*64+lane) is suppressed if any kept row of tile t suppresses it
+        for (int j0 = t + 1; j0 < tiles; j0 += 8) {
+            uint64_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const int cidx = j * 64 + lane;
+                w[u] = (j < tiles && cidx < n) ? maskT[(size_t)cidx * cb + t] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long bal = __ballot((w[u] & kept) != 0ull);
+                if (lane == j0 + u) remv |= bal;
+            }
         }
     }
     return nk;

@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="eight_20cm")
     ap.add_argument("--cls-bias", type=float, default=None, help="'trained-like' head bias (e.g. -4.6); default random init")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight per GPU: independent frames run on separate HIP streams (one pp_ctx each) so one "
                          "frame's kernel tails / small kernels overlap another frame's MFMA work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
