@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const size_t in_plane = (size_t)p.Hin * p.Win;
-    const int nchunk = p.Cin / KC;
-    const float4* wsrc = reinterpret_cast<const float4*>(p.w) + (size_t)blockIdx.y * nchunk * C::W4;
+    const int nchunk = (p.dbg & 16) ? 0 : p.Cin / KC;
+    const float4* wsrc = reinterpret_cast<const float4*>(p.w) + (size_t)blockIdx.y * (p.Cin / KC) * C::W4;
 
     float xv[C::PR][KC];
     f32x4 wv[C::WR];
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         });
 #undef PP_LOAD_OPS
         if (ch + 1 < nchunk && !(p.dbg & 1)) PP_STORE_CHUNK(ch + 1, buf ^ 1)
-        __syncthreads();
+        if (!(p.dbg & 8)) __syncthreads();
     }
 
     // ---- epilogue ----
@@ -385,6 +385,311 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convs (13 of the 16 convs, 141 of the 203 GFLOP):
+//   Y = A^T [ sum_cin (G g G^T) (.) (B^T d B) ] A      -> 16 MFMA "positions" instead of 9 taps per
+// 2x2 output tile, i.e. 2.25x fewer MFMAs, still exact-fp32 MFMA accumulation.
+// * one lane = one 2x2 output tile (N-tile = 16 tiles, TWT x 16/TWT), M = 16 output channels
+// * the weights are transformed on the host (fp64) and staged as a [16][KC][rows] LDS image
+// * the INPUT transform runs in registers: each lane reads the 4x4 raw patch of its tile from the
+//   same normalised/ReLU'd/zero-padded LDS patch the direct kernel uses (columns de-interleaved so the
+//   stride-2 tile walk is bank-conflict free) and forms its 16 B-operands with 32 adds -- no second
+//   LDS pass, no extra barrier
+// * the OUTPUT transform is per lane too (the 16 positions of a tile are 16 accumulators of one lane)
+// ------------------------------------------------------------------------------------------
+template <int TWT, int WM, int WN, int BTX, int KC>
+struct WinoCfg {
+    static constexpr int THT = 16 / TWT;
+    static constexpr int MT = 2;
+    static constexpr int BTY = WN / BTX;
+    static constexpr int PW = BTX * TWT * 2, PH = BTY * THT * 2;
+    static constexpr int IW = PW + 2, IH = PH + 2;
+    static constexpr int HALF = (IW + 1) / 2;
+    static constexpr int iwp()
+    {
+        int v = IW;
+        if (TWT == 16) return v;
+        while ((2 * v) % 32 != TWT) ++v;
+        return v;
+    }
+    static constexpr int IWP = iwp();
+    static constexpr int cs()
+    {
+        int v = IH * IWP;
+        while (v % 32 != 16) ++v;
+        return v;
+    }
+    static constexpr int CS = cs();
+    static constexpr int BM = WM * MT * 16;
+    static constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int NPOS = IH * IW;
+    static constexpr int PR = (NPOS + THREADS - 1) / THREADS;
+    static constexpr int W4 = 16 * KC * BMP / 4;
+    static constexpr int WR = (W4 + THREADS - 1) / THREADS;
+    static constexpr int LDS_IN = KC * CS;
+    static constexpr int LDS_W = 16 * KC * BMP;
+    static constexpr int LDS_FLOATS = 2 * (LDS_IN + LDS_W) + 2 * 320 + 2 * WN * BM;
+    static_assert(WN % BTX == 0, "tiles must form a rectangle");
+};
+
+template <int TWT, int WM, int WN, int BTX, int KC>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfma(const ConvP p)
+{
+    using C = WinoCfg<TWT, WM, WN, BTX, KC>;
+    constexpr int MT = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* il = smem;
+    float* wl = il + 2 * C::LDS_IN;
+    float* scl = wl + 2 * C::LDS_W;
+    float* shl = scl + 320;
+    float* red = shl + 320;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m = lane & 15, kq = lane >> 4;
+
+    const int nbx = (p.Wout + C::PW - 1) / C::PW;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int co0 = blockIdx.y * C::BM;
+    const int ox0 = bx * C::PW, oy0 = by * C::PH;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
+
+    if (p.pre == PRE_STATS) {
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                s += p.pre_acc[((size_t)r * p.Cin + c) * 2];
+                q += p.pre_acc[((size_t)r * p.Cin + c) * 2 + 1];
+            }
+            double mean = s * p.pre_inv_n;
+            double var = q * p.pre_inv_n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            double rstd = 1.0 / sqrt(var + (double)p.eps);
+            scl[c] = (float)rstd;
+            shl[c] = (float)(-mean * rstd);
+        }
+    } else if (p.pre == PRE_AFFINE) {
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            scl[c] = p.pre_scale[c];
+            shl[c] = p.pre_shift[c];
+        }
+    }
+
+    int goff[C::PR], loff[C::PR];
+    unsigned vmask = 0u;
+#pragma unroll
+    for (int r = 0; r < C::PR; ++r) {
+        const int pos = tid + r * C::THREADS;
+        const int iy = pos / C::IW, ix = pos - iy * C::IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool inb = pos < C::NPOS && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+        goff[r] = inb ? gy * p.Win + gx : 0;
+        vmask |= (inb ? 1u : 0u) << r;
+        loff[r] = pos < C::NPOS ? iy * C::IWP + (ix & 1) * C::HALF + (ix >> 1) : -1;
+    }
+
+    // this lane's tile: block-local tile coords -> top-left output pixel and raw-patch base
+    const int btx = wn % BTX, bty = wn / BTX;
+    const int ttx = btx * TWT + (m % TWT), tty = bty * C::THT + (m / TWT);
+    const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
+    const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
+    const int aoff = kq * C::BMP + wm * MT * 16 + m;
+
+    f32x4 acc[MT][16];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[i][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const size_t in_plane = (size_t)p.Hin * p.Win;
+    const int nchunk = p.Cin / KC;
+    const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(p.w) + (size_t)blockIdx.y * nchunk * C::W4;
+
+    float xv[C::PR][KC];
+    f32x4 wv[C::WR];
+
+#define WN_LOAD_CHUNK(CH)                                                                        \
+    {                                                                                            \
+        const float* base_ = p.in + (size_t)((CH) * KC) * in_plane;                              \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
+            _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
+        const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
+        _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
+            const int e_ = tid + r * C::THREADS;                                                 \
+            wv[r] = g_[e_ < C::W4 ? e_ : C::W4 - 1];                                             \
+        }                                                                                        \
+    }
+#define WN_STORE_CHUNK(CH, BUF)                                                                  \
+    {                                                                                            \
+        float* ib_ = il + (BUF) * C::LDS_IN;                                                     \
+        const int c0_ = (CH) * KC;                                                               \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                      \
+            if (loff[r] >= 0) {                                                                  \
+                const bool inb_ = (vmask >> r) & 1u;                                             \
+                _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                 \
+                    float v_ = xv[r][c];                                                         \
+                    if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, scl[c0_ + c], shl[c0_ + c]), 0.f); \
+                    ib_[c * C::CS + loff[r]] = inb_ ? v_ : 0.f;                                  \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+        f32x4* wb_ = reinterpret_cast<f32x4*>(wl + (BUF) * C::LDS_W);                            \
+        _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
+            const int e_ = tid + r * C::THREADS;                                                 \
+            if (e_ < C::W4) wb_[e_] = wv[r];                                                     \
+        }                                                                                        \
+    }
+// raw 4x4 patch of this lane's tile for channel quad C4 (this lane: channel C4*4 + kq)
+#define WN_READ_RAW(DST, C4)                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                         \
+            DST[i_ * 4 + j_] = ib[rbase + (C4) * 4 * C::CS + i_ * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
+// V = B^T d B
+#define WN_TRANSFORM(V, D)                                                                       \
+    {                                                                                            \
+        float t_[16];                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                       \
+            t_[0 + j_] = D[0 + j_] - D[8 + j_];                                                  \
+            t_[4 + j_] = D[4 + j_] + D[8 + j_];                                                  \
+            t_[8 + j_] = D[8 + j_] - D[4 + j_];                                                  \
+            t_[12 + j_] = D[4 + j_] - D[12 + j_];                                                \
+        }                                                                                        \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) {                                       \
+            V[a_ * 4 + 0] = t_[a_ * 4 + 0] - t_[a_ * 4 + 2];                                     \
+            V[a_ * 4 + 1] = t_[a_ * 4 + 1] + t_[a_ * 4 + 2];                                     \
+            V[a_ * 4 + 2] = t_[a_ * 4 + 2] - t_[a_ * 4 + 1];                                     \
+            V[a_ * 4 + 3] = t_[a_ * 4 + 1] - t_[a_ * 4 + 3];                                     \
+        }                                                                                        \
+    }
+
+    WN_LOAD_CHUNK(0)
+    __syncthreads();
+    WN_STORE_CHUNK(0, 0)
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk && !(p.dbg & 1)) WN_LOAD_CHUNK(ch + 1)
+        const float* ib = il + buf * C::LDS_IN;
+        const float* wb = wl + buf * C::LDS_W;
+        constexpr int NQ = KC / 4;
+        float draw[2][16], V[16], a[2][MT];
+        WN_READ_RAW(draw[0], 0)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[0][i] = wb[aoff + i * 16];
+        pp_steps<0, NQ * 16>([&](auto S) {
+            constexpr int s_ = decltype(S)::value;
+            constexpr int c4 = s_ / 16, xi = s_ % 16, cur = s_ & 1;
+            if constexpr (xi == 0) {
+                WN_TRANSFORM(V, draw[c4 & 1])
+                if constexpr (c4 + 1 < NQ) WN_READ_RAW(draw[(c4 + 1) & 1], c4 + 1)
+            }
+            if constexpr (s_ + 1 < NQ * 16) {
+                constexpr int n4 = (s_ + 1) / 16, nx = (s_ + 1) % 16;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[cur ^ 1][i] = wb[(nx * KC + n4 * 4) * C::BMP + aoff + i * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], V[xi], acc[i][xi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (ch + 1 < nchunk && !(p.dbg & 1)) WN_STORE_CHUNK(ch + 1, buf ^ 1)
+        __syncthreads();
+    }
+#undef WN_LOAD_CHUNK
+#undef WN_STORE_CHUNK
+#undef WN_READ_RAW
+#undef WN_TRANSFORM
+
+    // ---- epilogue: Y = A^T M A per lane, residual, store (float2 rows), statistics ----
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; return; }
+    const size_t out_plane = (size_t)p.Hout * p.Wout;
+    float ssum[MT][4], ssq[MT][4];
+    const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row0 = co0 + wm * MT * 16 + i * 16 + kq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_) {
+                const float m0 = acc[i][a_ * 4 + 0][r], m1 = acc[i][a_ * 4 + 1][r], m2 = acc[i][a_ * 4 + 2][r], m3 = acc[i][a_ * 4 + 3][r];
+                t0[a_] = m0 + m1 + m2;
+                t1[a_] = m1 - m2 - m3;
+            }
+            float y00 = t0[0] + t0[1] + t0[2], y01 = t1[0] + t1[1] + t1[2];
+            float y10 = t0[1] - t0[2] - t0[3], y11 = t1[1] - t1[2] - t1[3];
+            ssum[i][r] = 0.f;
+            ssq[i][r] = 0.f;
+            if (pix_ok && row0 + r < p.Cout) {
+                const size_t o = (size_t)(row0 + r) * out_plane + (size_t)opy * p.Wout + opx;
+                const bool two_x = opx + 1 < p.Wout, two_y = opy + 1 < p.Hout;
+                if (p.res) {
+                    if (two_x) {
+                        const float2 r0 = *reinterpret_cast<const float2*>(p.res + o);
+                        y00 += r0.x; y01 += r0.y;
+                        if (two_y) { const float2 r1 = *reinterpret_cast<const float2*>(p.res + o + p.Wout); y10 += r1.x; y11 += r1.y; }
+                    } else {
+                        y00 += p.res[o];
+                        if (two_y) y10 += p.res[o + p.Wout];
+                    }
+                }
+                if (two_x) {
+                    *reinterpret_cast<float2*>(p.out + o) = make_float2(y00, y01);
+                    if (two_y) *reinterpret_cast<float2*>(p.out + o + p.Wout) = make_float2(y10, y11);
+                } else {
+                    p.out[o] = y00;
+                    if (two_y) p.out[o + p.Wout] = y10;
+                }
+                float s_ = y00, q_ = y00 * y00;
+                if (two_x) { s_ += y01; q_ += y01 * y01; }
+                if (two_y) { s_ += y10; q_ += y10 * y10; if (two_x) { s_ += y11; q_ += y11 * y11; } }
+                ssum[i][r] = s_;
+                ssq[i][r] = q_;
+            }
+        }
+    }
+    if (p.stat_acc) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], q = ssq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o);
+                    q += __shfl_xor(q, o);
+                }
+                if (m == 0) {
+                    const int lr = wm * MT * 16 + i * 16 + kq * 4 + r;
+                    red[(wn * C::BM + lr) * 2] = s;
+                    red[(wn * C::BM + lr) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        for (int lr = tid; lr < C::BM; lr += C::THREADS) {
+            const int row = co0 + lr;
+            if (row >= p.Cout) continue;
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                s += (double)red[(w * C::BM + lr) * 2];
+                q += (double)red[(w * C::BM + lr) * 2 + 1];
+            }
+            double* dst = p.stat_acc + ((size_t)(blockIdx.x % NREP) * p.stat_C + row) * 2;
+            atomicAdd(dst, s);
+            atomicAdd(dst + 1, q);
+        }
+    }
+}
+
 // y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
 // Used for the [conv, norm, relu] head of each block, whose output is both a residual and the
 // input of the next InstanceNorm (pointpillars8_shared.py:133-137).
@@ -453,6 +758,7 @@ struct Variant { // one compiled tiling of conv_mfma
     int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
     size_t lds;
     char name[48];
+    int wino = 0; // 1: Winograd F(2x2,3x3) image (16 positions instead of 9 taps)
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -465,6 +771,20 @@ Variant make_variant()
     v.waves = WM * WN; v.pairs = MT * NT;
     v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
     snprintf(v.name, sizeof(v.name), "k%ds%d tw%d w%dx%d t%dx%d bx%d kc%d e%d", KS, STRIDE, TW, WM, WN, MT, NT, BTX, KC, EPI);
+    return v;
+}
+
+template <int TWT, int WM, int WN, int BTX, int KC>
+Variant make_wino()
+{
+    using C = WinoCfg<TWT, WM, WN, BTX, KC>;
+    Variant v;
+    v.kern = wino_mfma<TWT, WM, WN, BTX, KC>;
+    v.bm = C::BM; v.bmp = C::BMP; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
+    v.waves = WM * WN; v.pairs = 2 * 16;
+    v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    v.wino = 1;
+    snprintf(v.name, sizeof(v.name), "wino tw%d w%dx%d bx%d kc%d", TWT, WM, WN, BTX, KC);
     return v;
 }
 
@@ -546,6 +866,18 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu)
         conv_menu<3, 2, 8, EPI_PLAIN>(menu);
     } else {
         conv_menu<3, 1, 8, EPI_PLAIN>(menu);
+        //                     TWT WM WN BTX KC      output patch, rows
+        menu.push_back(make_wino<8, 1, 4, 1, 8>());  // 16x16 px, 32 rows
+        menu.push_back(make_wino<8, 1, 4, 2, 8>());  // 32x8 px, 32 rows
+        menu.push_back(make_wino<8, 2, 2, 1, 8>());  // 16x8 px, 64 rows
+        menu.push_back(make_wino<8, 2, 4, 1, 8>());  // 16x16 px, 64 rows, 8 waves
+        menu.push_back(make_wino<4, 1, 4, 2, 8>());  // 16x16 px, 32 rows
+        menu.push_back(make_wino<4, 2, 2, 1, 8>());  // 8x16 px, 64 rows
+        menu.push_back(make_wino<4, 2, 4, 2, 8>());  // 16x16 px, 64 rows, 8 waves
+        menu.push_back(make_wino<4, 1, 4, 1, 8>());  // 8x32 px, 32 rows
+        menu.push_back(make_wino<2, 1, 4, 2, 8>());  // 8x32 px (2x8-tile N-tiles), 32 rows
+        menu.push_back(make_wino<8, 1, 4, 1, 4>());
+        menu.push_back(make_wino<4, 1, 4, 2, 4>());
     }
 }
 
@@ -614,17 +946,32 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
     }
     L.rows = rows;
+    int taps_eff = taps;
+    if (v.wino) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<float> u((size_t)rows * L.cin * 16);
+        for (size_t rc = 0; rc < (size_t)rows * L.cin; ++rc) {
+            const float* g = &rowsW[rc * 9];
+            double t[4][3];
+            for (int a = 0; a < 4; ++a)
+                for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * g[0 * 3 + j] + G[a][1] * g[1 * 3 + j] + G[a][2] * g[2 * 3 + j];
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) u[rc * 16 + a * 4 + b] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        }
+        rowsW.swap(u);
+        taps_eff = 16;
+    }
     const int nblk = pp_div_up(rows, v.bm), nchunk = L.cin / v.kc;
-    std::vector<float> pk((size_t)nblk * nchunk * taps * v.kc * v.bmp, 0.f); // LDS image incl. row padding
+    std::vector<float> pk((size_t)nblk * nchunk * taps_eff * v.kc * v.bmp, 0.f); // LDS image incl. row padding
     for (int b = 0; b < nblk; ++b)
         for (int ch = 0; ch < nchunk; ++ch)
-            for (int t = 0; t < taps; ++t)
+            for (int t = 0; t < taps_eff; ++t)
                 for (int k = 0; k < v.kc; ++k)
                     for (int mm = 0; mm < v.bm; ++mm) {
                         const int row = b * v.bm + mm;
                         if (row >= rows) continue;
-                        pk[((((size_t)b * nchunk + ch) * taps + t) * v.kc + k) * v.bmp + mm] =
-                            rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps + t];
+                        pk[((((size_t)b * nchunk + ch) * taps_eff + t) * v.kc + k) * v.bmp + mm] =
+                            rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps_eff + t];
                     }
     if (L.w) (void)hipFree(L.w);
     PP_HIP(hipMalloc((void**)&L.w, pk.size() * sizeof(float)));
@@ -727,6 +1074,10 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     std::vector<Variant> menu;
     layer_menu(L.kind, L.stride, L.up, menu);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
+    if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
+        for (const Variant& v : menu)
+            if (variant_ok(v, rows) && strstr(v.name, force)) { L.var = v; return 0; }
+    }
     auto hit = tune_cache().find(sig);
     if (hit != tune_cache().end()) {
         for (const Variant& v : menu)
