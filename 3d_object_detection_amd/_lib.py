@@ -32,6 +32,7 @@ class PPConfig(ctypes.Structure):
         ("nms_post_max", c_i32),
         ("nms_iou_threshold", c_f),
         ("score_threshold", c_f),
+        ("max_batch", c_i32),
     ]
 
 
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "pp_head": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "pp_postprocess": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int, c_p]),
     "pp_infer_frame": (ctypes.c_int, [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_infer_batch": (ctypes.c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i32), ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
     "pp_box_decode": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p]),
     "pp_corners2d": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p]),
     "pp_standup2d": (ctypes.c_int, [c_p, c_p, c_i64, c_p]),

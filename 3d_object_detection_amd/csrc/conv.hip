@@ -74,6 +74,9 @@ struct ConvP {
     int n_cls, n_box; // 9, 63 (dir = rest up to n_rows)
     int n_rows;       // 90
     int dbg;          // diagnostics only (PP_CONV_DBG): 1 = skip staging after chunk 0, 4 = skip epilogue
+    // batch: blockIdx.z = frame; strides in elements between consecutive frames
+    size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
+    size_t pre_fs, stat_fs;                        // doubles
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -129,6 +132,16 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
     float* scl = wl + 2 * C::LDS_W;            // [320] scale
     float* shl = scl + 320;                    // [320] shift
     float* red = shl + 320;                    // [WN][BM][2]
+    // frame of this workgroup (batched launch)
+    const size_t fz = blockIdx.z;
+    const float* __restrict__ gin = p.in + fz * p.in_fs;
+    float* __restrict__ gout = p.out + fz * p.out_fs;
+    const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
+    const double* __restrict__ gpre = p.pre_acc ? p.pre_acc + fz * p.pre_fs : nullptr;
+    double* __restrict__ gstat = p.stat_acc ? p.stat_acc + fz * p.stat_fs : nullptr;
+    float* __restrict__ gbox = p.out_box ? p.out_box + fz * p.box_fs : nullptr;
+    float* __restrict__ gdir = p.out_dir ? p.out_dir + fz * p.dir_fs : nullptr;
+    (void)gbox; (void)gdir;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,8 +161,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
             double s = 0.0, q = 0.0;
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                s += p.pre_acc[((size_t)r * p.Cin + c) * 2];
-                q += p.pre_acc[((size_t)r * p.Cin + c) * 2 + 1];
+                s += gpre[((size_t)r * p.Cin + c) * 2];
+                q += gpre[((size_t)r * p.Cin + c) * 2 + 1];
             }
             double mean = s * p.pre_inv_n;
             double var = q * p.pre_inv_n - mean * mean;
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
 #define PP_LOAD_CHUNK(CH)                                                                        \
     {                                                                                            \
-        const float* base_ = p.in + (size_t)((CH) * KC) * in_plane;                              \
+        const float* base_ = gin + (size_t)((CH) * KC) * in_plane;                              \
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
             _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
         const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
     }
 
     // ---- epilogue ----
-    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; return; }
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) gout[0] = 1.f; return; }
     const size_t out_plane = (size_t)p.Hout * p.Wout;
     float ssum[MT][4], ssq[MT][4];
 #pragma unroll
@@ -306,15 +319,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
                 for (int r = 0; r < 4; ++r) {
                     const size_t o = (size_t)(row0 + r) * out_plane + pix;
                     float x = v[r];
-                    if (p.res) x += p.res[o];
-                    p.out[o] = x;
+                    if (gres) x += gres[o];
+                    gout[o] = x;
                     ssum[i][r] += x;
                     ssq[i][r] += x * x;
                 }
             } else if (EPI == EPI_UP2) { // rows (co*4 + dy*2 + dx) -> out[co][2y+dy][2x+dx]
                 const int co = row0 >> 2;
                 const size_t W2 = (size_t)p.Wout * 2;
-                float* o = p.out + (size_t)co * out_plane * 4 + (size_t)(2 * opy[j]) * W2 + 2 * opx[j];
+                float* o = gout + (size_t)co * out_plane * 4 + (size_t)(2 * opy[j]) * W2 + 2 * opx[j];
                 *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
                 *reinterpret_cast<float2*>(o + W2) = make_float2(v[2], v[3]);
 #pragma unroll
@@ -322,7 +335,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
             } else if (EPI == EPI_UP4) { // rows (co*16 + dy*4 + dx) -> out[co][4y+dy][4x+dx]
                 const int co = row0 >> 4, dy = (row0 >> 2) & 3;
                 const size_t W4o = (size_t)p.Wout * 4;
-                float* o = p.out + (size_t)co * out_plane * 16 + (size_t)(4 * opy[j] + dy) * W4o + 4 * opx[j];
+                float* o = gout + (size_t)co * out_plane * 16 + (size_t)(4 * opy[j] + dy) * W4o + 4 * opx[j];
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
@@ -333,20 +346,20 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
                     if (row >= p.n_rows) continue;
                     const float x = v[r] + p.bias[row];
                     if (row < p.n_cls) {
-                        p.out[(size_t)row * out_plane + pix] = x;
+                        gout[(size_t)row * out_plane + pix] = x;
                     } else if (row < p.n_cls + p.n_box) {
                         const int q = row - p.n_cls, a = q / 7, k = q - a * 7;
-                        p.out_box[((size_t)a * out_plane + pix) * 7 + k] = x;
+                        gbox[((size_t)a * out_plane + pix) * 7 + k] = x;
                     } else {
                         const int q = row - p.n_cls - p.n_box, a = q >> 1, k = q & 1;
-                        p.out_dir[((size_t)a * out_plane + pix) * 2 + k] = x;
+                        gdir[((size_t)a * out_plane + pix) * 2 + k] = x;
                     }
                 }
             }
         }
     }
 
-    if (EPI != EPI_HEAD && p.stat_acc) {
+    if (EPI != EPI_HEAD && gstat) {
         // reduce over the 16 pixel lanes, then over the WN waves through LDS, then fp64 atomics
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -378,7 +391,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
             if (EPI == EPI_UP2) { if (lr & 3) continue; ch = row >> 2; }
             else if (EPI == EPI_UP4) { if (lr & 3) continue; ch = row >> 4; }
             else ch = row;
-            double* dst = p.stat_acc + ((size_t)(blockIdx.x % NREP) * p.stat_C + ch) * 2;
+            double* dst = gstat + ((size_t)(blockIdx.x % NREP) * p.stat_C + ch) * 2;
             atomicAdd(dst, s);
             atomicAdd(dst + 1, q);
         }
@@ -444,6 +457,16 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     float* scl = wl + 2 * C::LDS_W;
     float* shl = scl + 320;
     float* red = shl + 320;
+    // frame of this workgroup (batched launch)
+    const size_t fz = blockIdx.z;
+    const float* __restrict__ gin = p.in + fz * p.in_fs;
+    float* __restrict__ gout = p.out + fz * p.out_fs;
+    const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
+    const double* __restrict__ gpre = p.pre_acc ? p.pre_acc + fz * p.pre_fs : nullptr;
+    double* __restrict__ gstat = p.stat_acc ? p.stat_acc + fz * p.stat_fs : nullptr;
+    float* __restrict__ gbox = p.out_box ? p.out_box + fz * p.box_fs : nullptr;
+    float* __restrict__ gdir = p.out_dir ? p.out_dir + fz * p.dir_fs : nullptr;
+    (void)gbox; (void)gdir;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -462,8 +485,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             double s = 0.0, q = 0.0;
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                s += p.pre_acc[((size_t)r * p.Cin + c) * 2];
-                q += p.pre_acc[((size_t)r * p.Cin + c) * 2 + 1];
+                s += gpre[((size_t)r * p.Cin + c) * 2];
+                q += gpre[((size_t)r * p.Cin + c) * 2 + 1];
             }
             double mean = s * p.pre_inv_n;
             double var = q * p.pre_inv_n - mean * mean;
@@ -514,7 +537,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 
 #define WN_LOAD_CHUNK(CH)                                                                        \
     {                                                                                            \
-        const float* base_ = p.in + (size_t)((CH) * KC) * in_plane;                              \
+        const float* base_ = gin + (size_t)((CH) * KC) * in_plane;                              \
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
             _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
         const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
@@ -608,7 +631,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #undef WN_TRANSFORM
 
     // ---- epilogue: Y = A^T M A per lane, residual, store (float2 rows), statistics ----
-    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; return; }
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) gout[0] = 1.f; return; }
     const size_t out_plane = (size_t)p.Hout * p.Wout;
     float ssum[MT][4], ssq[MT][4];
     const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
@@ -631,22 +654,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             if (pix_ok && row0 + r < p.Cout) {
                 const size_t o = (size_t)(row0 + r) * out_plane + (size_t)opy * p.Wout + opx;
                 const bool two_x = opx + 1 < p.Wout, two_y = opy + 1 < p.Hout;
-                if (p.res) {
+                if (gres) {
                     if (two_x) {
-                        const float2 r0 = *reinterpret_cast<const float2*>(p.res + o);
+                        const float2 r0 = *reinterpret_cast<const float2*>(gres + o);
                         y00 += r0.x; y01 += r0.y;
-                        if (two_y) { const float2 r1 = *reinterpret_cast<const float2*>(p.res + o + p.Wout); y10 += r1.x; y11 += r1.y; }
+                        if (two_y) { const float2 r1 = *reinterpret_cast<const float2*>(gres + o + p.Wout); y10 += r1.x; y11 += r1.y; }
                     } else {
-                        y00 += p.res[o];
-                        if (two_y) y10 += p.res[o + p.Wout];
+                        y00 += gres[o];
+                        if (two_y) y10 += gres[o + p.Wout];
                     }
                 }
                 if (two_x) {
-                    *reinterpret_cast<float2*>(p.out + o) = make_float2(y00, y01);
-                    if (two_y) *reinterpret_cast<float2*>(p.out + o + p.Wout) = make_float2(y10, y11);
+                    *reinterpret_cast<float2*>(gout + o) = make_float2(y00, y01);
+                    if (two_y) *reinterpret_cast<float2*>(gout + o + p.Wout) = make_float2(y10, y11);
                 } else {
-                    p.out[o] = y00;
-                    if (two_y) p.out[o + p.Wout] = y10;
+                    gout[o] = y00;
+                    if (two_y) gout[o + p.Wout] = y10;
                 }
                 float s_ = y00, q_ = y00 * y00;
                 if (two_x) { s_ += y01; q_ += y01 * y01; }
@@ -656,7 +679,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             }
         }
     }
-    if (p.stat_acc) {
+    if (gstat) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -683,7 +706,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
                 s += (double)red[(w * C::BM + lr) * 2];
                 q += (double)red[(w * C::BM + lr) * 2 + 1];
             }
-            double* dst = p.stat_acc + ((size_t)(blockIdx.x % NREP) * p.stat_C + row) * 2;
+            double* dst = gstat + ((size_t)(blockIdx.x % NREP) * p.stat_C + row) * 2;
             atomicAdd(dst, s);
             atomicAdd(dst + 1, q);
         }
@@ -696,9 +719,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
                                                        int pre, const double* __restrict__ pre_acc,
                                                        const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
-                                                       double inv_n, float eps, double* __restrict__ stat_acc)
+                                                       double inv_n, float eps, double* __restrict__ stat_acc,
+                                                       size_t x_fs, size_t acc_fs)
 {
     const int c = blockIdx.y;
+    x += blockIdx.z * x_fs;
+    y += blockIdx.z * x_fs;
+    if (pre_acc) pre_acc += blockIdx.z * acc_fs;
+    if (stat_acc) stat_acc += blockIdx.z * acc_fs;
     float sc, sh;
     if (pre == PRE_STATS) {
         double s = 0.0, q = 0.0;
@@ -805,6 +833,7 @@ struct NormRef { // where a consumer finds the producer's normalisation
     float* shift = nullptr;
     int C = 0;
     double inv_n = 0.0;
+    size_t fs = 0; // doubles between frames of `acc`
 };
 
 struct pp_net {
@@ -979,9 +1008,11 @@ int pack_layer(pp_ctx* ctx, Layer& L)
     return 0;
 }
 
+constexpr size_t STAT_FS = (size_t)24 * NREP * 320 * 2; // doubles of statistics per frame
+
 int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, float* out, const float* res,
                 const NormRef& pre, double* stat_acc, int stat_C, int Hout, int Wout, hipStream_t stream,
-                float* out_box = nullptr, float* out_dir = nullptr)
+                float* out_box = nullptr, float* out_dir = nullptr, int B = 1, size_t out_fs = 0, size_t in_fs = 0)
 {
     pp_net* net = (pp_net*)ctx->net;
     ConvP p;
@@ -995,8 +1026,18 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.bias = net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
     p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
     { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
+    {   // frame strides of a batched launch (every per-frame tensor is stored [B][...])
+        const size_t hw = (size_t)Hout * Wout;
+        p.in_fs = in_fs ? in_fs : (size_t)L.cin * Hin * Win;
+        p.out_fs = out_fs ? out_fs : (L.kind == 2 ? (size_t)9 * hw : (size_t)L.rows * hw);
+        p.res_fs = p.out_fs;
+        p.box_fs = (size_t)63 * hw;
+        p.dir_fs = (size_t)18 * hw;
+        p.pre_fs = pre.fs;
+        p.stat_fs = STAT_FS;
+    }
     const Variant& v = L.var;
-    dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm));
+    dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm), B);
     const bool tag = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
     if (tag) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -1006,7 +1047,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
             ctx->prof_ev.push_back(a);
             ctx->prof_ev.push_back(b);
         }
-        ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0;
+        ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0 * B;
         PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used], stream));
     }
     hipLaunchKernelGGL(v.kern, grid, dim3(v.threads), v.lds, stream, p);
@@ -1070,7 +1111,8 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
 {
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
-    snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind);
+    snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d b%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind,
+             ctx->max_batch < 4 ? ctx->max_batch : 4);
     std::vector<Variant> menu;
     layer_menu(L.kind, L.stride, L.up, menu);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
@@ -1102,7 +1144,8 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
         float ms = 0.f;
         for (int it = 0; it < 4; ++it) {
             if (it == 1) PP_HIP(hipEventRecord(e0, 0));
-            rc = launch_conv(ctx, L, tin, Hin, Win, (L.kind == 2) ? ctx->f_cls : tout, nullptr, pre, st, stC, Hout, Wout, 0, ctx->f_box, ctx->f_dir);
+            rc = launch_conv(ctx, L, tin, Hin, Win, (L.kind == 2) ? ctx->f_cls : tout, nullptr, pre, st, stC, Hout, Wout, 0, ctx->f_box, ctx->f_dir,
+                             ctx->max_batch < 4 ? ctx->max_batch : 4, 4, 4); // batched like production; frames alias the scratch buffers
             if (rc) return rc;
         }
         PP_HIP(hipEventRecord(e1, 0));
@@ -1129,10 +1172,10 @@ int pp_net_create(pp_ctx* ctx)
     const int H = ctx->H, W = ctx->W;
     for (int l = 0; l < 3; ++l)
         for (int b = 0; b < 4; ++b)
-            PP_HIP(hipMalloc((void**)&net->buf[l][b], (size_t)kC[l] * ((H >> l) + 1) * ((W >> l) + 1) * sizeof(float)));
-    PP_HIP(hipMalloc((void**)&net->up, (size_t)320 * H * W * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&net->buf[l][b], (size_t)ctx->max_batch * kC[l] * ((H >> l) + 1) * ((W >> l) + 1) * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->up, (size_t)ctx->max_batch * 320 * H * W * sizeof(float)));
     // statistics accumulators: one slot of [NREP][256][2] doubles per normalisation site (<= 24 sites)
-    net->stats_bytes = (size_t)24 * NREP * 320 * 2 * sizeof(double);
+    net->stats_bytes = (size_t)ctx->max_batch * 24 * NREP * 320 * 2 * sizeof(double);
     PP_HIP(hipMalloc((void**)&net->stats, net->stats_bytes));
     PP_HIP(hipMalloc((void**)&net->bn_scale, (size_t)24 * 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->bn_shift, (size_t)24 * 320 * sizeof(float)));
@@ -1239,8 +1282,8 @@ int pp_net_commit(pp_ctx* ctx)
         const bool can_tune = tune && (H % 4 == 0) && (W % 4 == 0);
         if (can_tune) {
             const size_t nin = std::max((size_t)64 * ctx->gx * ctx->gy, (size_t)320 * H * W);
-            PP_HIP(hipMalloc((void**)&tin, nin * sizeof(float)));
-            PP_HIP(hipMalloc((void**)&tout, (size_t)320 * H * W * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&tin, (nin + 256) * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&tout, ((size_t)320 * H * W + 256) * sizeof(float)));
             hipLaunchKernelGGL(fill_pattern, dim3(2048), dim3(256), 0, 0, tin, nin);
         }
         for (Layer& L : net->layers) {
@@ -1317,6 +1360,7 @@ NormRef norm_ref(pp_ctx* ctx, int site, int C, int coff, size_t count)
         r.mode = PRE_STATS;
         r.acc = net->stats + (size_t)site * NREP * 320 * 2;
         r.inv_n = 1.0 / (double)count;
+        r.fs = STAT_FS;
     }
     return r;
 }
@@ -1327,12 +1371,13 @@ double* stat_slot(pp_ctx* ctx, int site)
     return ((pp_net*)ctx->net)->stats + (size_t)site * NREP * 320 * 2;
 }
 
-int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const NormRef& pre, double* stat, hipStream_t stream)
+int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const NormRef& pre, double* stat, hipStream_t stream,
+                     int B = 1)
 {
     int bx = pp_div_up(HW / 4, 256 * 4);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(norm_relu_stats, dim3(bx, C), dim3(256), 0, stream, x, y, C, HW, pre.mode, pre.acc, pre.scale,
-                       pre.shift, pre.inv_n, 1e-3f, stat);
+    hipLaunchKernelGGL(norm_relu_stats, dim3(bx, C, B), dim3(256), 0, stream, x, y, C, HW, pre.mode, pre.acc, pre.scale,
+                       pre.shift, pre.inv_n, 1e-3f, stat, (size_t)C * HW, STAT_FS);
     PP_HIP(hipGetLastError());
     return 0;
 }
@@ -1341,30 +1386,33 @@ int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const
 
 // canvas [64,gx,gy] -> up [320,H,W] PRE-norm (+ statistics); the head (or pp_backbone's final pass)
 // applies the last norm + ReLU.
-int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream)
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream)
 {
     pp_net* net = (pp_net*)ctx->net;
     const int H = ctx->H, W = ctx->W;
     if ((H % 4) || (W % 4)) return pp_fail(ctx, PP_E_ARG, "backbone: BEV grid must be a multiple of 8 in x and y");
-    if (ctx->cfg.norm_kind == 0) PP_HIP(hipMemsetAsync(net->stats, 0, net->stats_bytes, stream));
+    if (nb < 1 || nb > ctx->max_batch) return pp_fail(ctx, PP_E_ARG, "backbone: batch exceeds cfg.max_batch");
+    if (ctx->cfg.norm_kind == 0) PP_HIP(hipMemsetAsync(net->stats, 0, STAT_FS * sizeof(double) * nb, stream));
     NormRef raw;
     const float* x = canvas;
     int Hin = ctx->gx, Win = ctx->gy;
     size_t li = 0;
     const int up_coff[3] = {0, 64, 192};
+    const size_t up_fs = (size_t)320 * H * W;
     for (int b = 0; b < 3; ++b) {
         const int c = kC[b];
         const int h = H >> b, w = W >> b;
         const size_t cnt = (size_t)h * w;
-        float** B = net->buf[b];
+        float** Bf = net->buf[b];
         int rc;
-        // strided conv (raw input) -> B[0] + stats(site 0)
-        if ((rc = launch_conv(ctx, net->layers[li++], x, Hin, Win, B[0], nullptr, raw, stat_slot(ctx, site_block(b, 0)), c, h, w, stream))) return rc;
-        // y = relu(norm(B[0])) -> B[1] + stats(site 1) (the first Resnet2 unit's leading norm)
-        if ((rc = launch_norm_relu(ctx, B[0], B[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
-                                   stat_slot(ctx, site_block(b, 1)), stream))) return rc;
-        float* cur = B[1];
-        float* spare[3] = {B[0], B[2], B[3]};
+        // strided conv (raw input) -> Bf[0] + stats(site 0)
+        if ((rc = launch_conv(ctx, net->layers[li++], x, Hin, Win, Bf[0], nullptr, raw, stat_slot(ctx, site_block(b, 0)), c, h, w, stream,
+                              nullptr, nullptr, nb))) return rc;
+        // y = relu(norm(Bf[0])) -> Bf[1] + stats(site 1) (the first Resnet2 unit's leading norm)
+        if ((rc = launch_norm_relu(ctx, Bf[0], Bf[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
+                                   stat_slot(ctx, site_block(b, 1)), stream, nb))) return rc;
+        float* cur = Bf[1];
+        float* spare[3] = {Bf[0], Bf[2], Bf[3]};
         const int nunits = (b == 0) ? 2 : 3;
         for (int u = 0; u < nunits; ++u) {
             const int nl = (u == nunits - 1) ? 0 : 1;
@@ -1375,28 +1423,24 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream)
             double* out_stat = last ? nullptr : stat_slot(ctx, site_block(b, 1 + 2 * (u + 1)));
             if (nl == 1) {
                 if ((rc = launch_conv(ctx, net->layers[li++], cur, h, w, t1, nullptr, norm_ref(ctx, site_block(b, 1 + 2 * u), c, 0, cnt),
-                                      stat_slot(ctx, site_block(b, 2 + 2 * u)), c, h, w, stream))) return rc;
+                                      stat_slot(ctx, site_block(b, 2 + 2 * u)), c, h, w, stream, nullptr, nullptr, nb))) return rc;
                 if ((rc = launch_conv(ctx, net->layers[li++], t1, h, w, t2, cur, norm_ref(ctx, site_block(b, 2 + 2 * u), c, 0, cnt),
-                                      out_stat, c, h, w, stream))) return rc;
-                // rotate buffers: t2 becomes current, old current + t1 are free
-                spare[1] = cur;
+                                      out_stat, c, h, w, stream, nullptr, nullptr, nb))) return rc;
+                spare[1] = cur; // t2 becomes current; old current and t1 are free
                 cur = t2;
             } else {
                 if ((rc = launch_conv(ctx, net->layers[li++], cur, h, w, t1, cur, norm_ref(ctx, site_block(b, 1 + 2 * u), c, 0, cnt),
-                                      out_stat, c, h, w, stream))) return rc;
+                                      out_stat, c, h, w, stream, nullptr, nullptr, nb))) return rc;
                 spare[0] = cur;
                 cur = t1;
             }
         }
-        // deconv on the raw block output -> up[coff..] + stats (site 7, channel offset)
+        // deconv on the raw block output -> channel slice of up[320,H,W] + stats (site 7, channel offset)
         {
             const Layer& L = net->layers[li++];
             double* st = stat_slot(ctx, 7);
-            // deconv statistics live in one 320-channel slot; pass the slot shifted to this map's channels
-            double* st_off = st ? st + (size_t)up_coff[b] * 2 : nullptr;
-            (void)st_off;
             if ((rc = launch_conv(ctx, L, cur, h, w, net->up + (size_t)up_coff[b] * H * W, nullptr, raw, st ? st + (size_t)up_coff[b] * 2 : nullptr,
-                                  320, h, w, stream))) return rc;
+                                  320, h, w, stream, nullptr, nullptr, nb, up_fs))) return rc;
         }
         x = cur;
         Hin = h;
@@ -1405,17 +1449,17 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream)
     return 0;
 }
 
-static int pp_head_impl(pp_ctx* ctx, const float* in, const NormRef& pre, float* cls, float* box, float* dir, hipStream_t stream)
+static int pp_head_impl(pp_ctx* ctx, const float* in, const NormRef& pre, float* cls, float* box, float* dir, int nb, hipStream_t stream)
 {
     pp_net* net = (pp_net*)ctx->net;
-    return launch_conv(ctx, net->layers.back(), in, ctx->H, ctx->W, cls, nullptr, pre, nullptr, 0, ctx->H, ctx->W, stream, box, dir);
+    return launch_conv(ctx, net->layers.back(), in, ctx->H, ctx->W, cls, nullptr, pre, nullptr, 0, ctx->H, ctx->W, stream, box, dir, nb);
 }
 
-int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, hipStream_t stream)
+int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, int nb, hipStream_t stream)
 {
     pp_net* net = (pp_net*)ctx->net;
     NormRef pre = norm_ref(ctx, 7, 320, 0, (size_t)ctx->H * ctx->W);
-    return pp_head_impl(ctx, net->up, pre, cls, box, dir, stream);
+    return pp_head_impl(ctx, net->up, pre, cls, box, dir, nb, stream);
 }
 
 extern "C" int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, void* stream_)
@@ -1424,7 +1468,7 @@ extern "C" int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, voi
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_backbone: weights not committed");
     if (!canvas || !rpn_out) return pp_fail(ctx, PP_E_ARG, "pp_backbone: null pointer");
-    int rc = pp_run_backbone(ctx, canvas, stream);
+    int rc = pp_run_backbone(ctx, canvas, 1, stream);
     if (rc) return rc;
     pp_net* net = (pp_net*)ctx->net;
     const int HW = ctx->H * ctx->W;
@@ -1439,7 +1483,7 @@ extern "C" int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box
     if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_head: weights not committed");
     if (!rpn_out || !cls || !box || !dir) return pp_fail(ctx, PP_E_ARG, "pp_head: null pointer");
     NormRef raw; // rpn_out is already normalised + ReLU'd
-    return pp_head_impl(ctx, rpn_out, raw, cls, box, dir, stream);
+    return pp_head_impl(ctx, rpn_out, raw, cls, box, dir, 1, stream);
 }
 
 extern "C" int pp_profile_begin(pp_ctx* ctx)

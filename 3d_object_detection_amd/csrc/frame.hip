@@ -1,20 +1,48 @@
-// pp_infer_frame: the whole hot path for one cloud on one stream, no host synchronisation
+// pp_infer_frame / pp_infer_batch: the whole hot path on one stream, no host synchronisation
 // (train.py:222-237 crosses the host/device boundary >= 3 times and synchronises >= 14 times per frame).
+// A batch carries nb independent frames through ONE set of conv/deconv/head launches (grid.z = frame):
+// the launches get several rounds of workgroups, so the prologue/epilogue of one round overlaps the MFMA
+// phase of the next instead of being exposed once per frame and layer.
 #include "pp_common.h"
 
-extern "C" int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream_)
+extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int32_t* n_h, int nb, float* det, int32_t* det_count,
+                              int nms_mode, void* stream_)
 {
     if (!ctx) return PP_E_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_infer_frame: weights not committed");
-    if (ctx->A == 0) return pp_fail(ctx, PP_E_STATE, "pp_infer_frame: call pp_set_anchors first");
-    if (!det || !det_count) return pp_fail(ctx, PP_E_ARG, "pp_infer_frame: null pointer");
+    if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_infer_batch: weights not committed");
+    if (ctx->A == 0) return pp_fail(ctx, PP_E_STATE, "pp_infer_batch: call pp_set_anchors first");
+    if (!det || !det_count || !pts_h || !n_h) return pp_fail(ctx, PP_E_ARG, "pp_infer_batch: null pointer");
+    if (nb < 1 || nb > ctx->max_batch) return pp_fail(ctx, PP_E_ARG, "pp_infer_batch: nb exceeds cfg.max_batch");
+    const pp_config& c = ctx->cfg;
+    const size_t mv = (size_t)c.max_voxels;
+    const size_t vs = mv * c.max_num_points * c.num_point_features;
+    const size_t plane = (size_t)ctx->gx * ctx->gy * 64;
+    const size_t A = (size_t)ctx->A;
     int rc;
-    if ((rc = pp_voxelize(ctx, pts, n, ctx->cfg.num_point_features, ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, stream))) return rc;
-    if ((rc = pp_anchor_mask(ctx, ctx->f_coors, ctx->f_num, ctx->f_mask, stream))) return rc;
-    if ((rc = pp_pfn(ctx, ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, ctx->f_feat, stream))) return rc;
-    if ((rc = pp_scatter(ctx, ctx->f_feat, ctx->f_coors, ctx->f_num, ctx->f_canvas, stream))) return rc;
-    if ((rc = pp_run_backbone(ctx, ctx->f_canvas, stream))) return rc;
-    if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, stream))) return rc;
-    return pp_postprocess(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, ctx->f_mask, det, det_count, nms_mode, stream);
+    for (int b = 0; b < nb; ++b) {
+        float* vox = ctx->f_voxels + b * vs;
+        int32_t* coors = ctx->f_coors + b * mv * 3;
+        int32_t* npts = ctx->f_npts + b * mv;
+        int32_t* num = ctx->f_num + b * 4;
+        float* feat = ctx->f_feat + b * mv * 64;
+        if ((rc = pp_voxelize(ctx, pts_h[b], n_h[b], c.num_point_features, vox, coors, npts, num, stream))) return rc;
+        if ((rc = pp_anchor_mask(ctx, coors, num, ctx->f_mask + b * A, stream))) return rc;
+        if ((rc = pp_pfn(ctx, vox, coors, npts, num, feat, stream))) return rc;
+        if ((rc = pp_scatter(ctx, feat, coors, num, ctx->f_canvas + b * plane, stream))) return rc;
+    }
+    if ((rc = pp_run_backbone(ctx, ctx->f_canvas, nb, stream))) return rc;
+    if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
+    const size_t rows = (size_t)c.num_classes * c.nms_post_max;
+    for (int b = 0; b < nb; ++b)
+        if ((rc = pp_postprocess(ctx, ctx->f_cls + b * A, ctx->f_box + b * A * 7, ctx->f_dir + b * A * 2, ctx->f_mask + b * A,
+                                 det + b * rows * 9, det_count + b * PP_DET_COUNT_STRIDE, nms_mode, stream))) return rc;
+    return 0;
+}
+
+extern "C" int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream)
+{
+    const float* p1[1] = {pts};
+    const int32_t n1[1] = {n};
+    return pp_infer_batch(ctx, p1, n1, 1, det, det_count, nms_mode, stream);
 }

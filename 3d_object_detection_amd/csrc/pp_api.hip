@@ -47,15 +47,15 @@ static int create_impl(pp_ctx* ctx)
     PP_HIP(dalloc(&ctx->pfn_scale, 64));
     PP_HIP(dalloc(&ctx->pfn_shift, 64));
     // frame buffers for the fused path
-    size_t mv = (size_t)c.max_voxels;
+    size_t mv = (size_t)c.max_voxels * ctx->max_batch; // per-frame buffers are stored [max_batch][...]
     PP_HIP(dalloc(&ctx->f_voxels, mv * c.max_num_points * c.num_point_features));
     PP_HIP(dalloc(&ctx->f_coors, mv * 3));
     PP_HIP(dalloc(&ctx->f_npts, mv));
-    PP_HIP(dalloc(&ctx->f_num, 4));
+    PP_HIP(dalloc(&ctx->f_num, 4 * (size_t)ctx->max_batch));
     PP_HIP(dalloc(&ctx->f_feat, mv * 64));
-    PP_HIP(dalloc(&ctx->f_canvas, (size_t)64 * ctx->gx * ctx->gy));
+    PP_HIP(dalloc(&ctx->f_canvas, (size_t)ctx->max_batch * 64 * ctx->gx * ctx->gy));
     size_t HW = (size_t)ctx->H * ctx->W;
-    size_t Amax = HW * c.num_anchor_per_loc;
+    size_t Amax = HW * c.num_anchor_per_loc * ctx->max_batch;
     PP_HIP(dalloc(&ctx->f_mask, Amax));
     PP_HIP(dalloc(&ctx->f_cls, Amax));
     PP_HIP(dalloc(&ctx->f_box, Amax * 7));
@@ -76,12 +76,15 @@ extern "C" pp_ctx* pp_create(int device, const pp_config* cfg)
     }
     if (cfg->max_voxels <= 0 || cfg->max_num_points <= 0 || cfg->max_points <= 0 || cfg->num_classes <= 0 ||
         cfg->num_classes > PP_MAX_CLASSES || cfg->nms_pre_max <= 0 || cfg->nms_pre_max > 4096 ||
-        cfg->nms_post_max <= 0 || cfg->nms_post_max > cfg->nms_pre_max || cfg->nms_post_max > 1024) {
+        cfg->nms_post_max <= 0 || cfg->nms_post_max > cfg->nms_pre_max || cfg->nms_post_max > 1024 || cfg->max_batch < 0 ||
+        cfg->max_batch > 64) {
         pp_fail(nullptr, PP_E_ARG, "pp_create: size out of range");
         return nullptr;
     }
     pp_ctx* ctx = new pp_ctx();
     ctx->cfg = *cfg;
+    ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 1;
+    ctx->cfg.max_batch = ctx->max_batch;
     ctx->device = device;
     ctx->gx = cfg->grid_size[0];
     ctx->gy = cfg->grid_size[1];

@@ -36,6 +36,7 @@ struct pp_ctx {
     std::string err;
     // ---- geometry ----
     int gx = 0, gy = 0, H = 0, W = 0; // BEV grid and level-1 feature map (H = gx/2 along x, W = gy/2 along y)
+    int max_batch = 1;                // frames per batched launch (cfg.max_batch)
     int64_t A = 0;                    // anchors
     // ---- voxeliser workspace ----
     int32_t* cell_first = nullptr; // [gx*gy*gz] first point index per cell
@@ -78,8 +79,8 @@ int pp_net_create(pp_ctx* ctx);
 void pp_net_destroy(pp_ctx* ctx);
 int pp_net_commit(pp_ctx* ctx);
 int pp_post_create(pp_ctx* ctx);
-int pp_run_backbone(pp_ctx* ctx, const float* canvas, hipStream_t stream);          // canvas -> pre-norm [320,H,W] + stats
-int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, hipStream_t stream); // norm+ReLU fused in the prologue
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream);          // nb canvases -> pre-norm [nb,320,H,W] + stats
+int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, int nb, hipStream_t stream); // norm+ReLU fused in the prologue
 void pp_post_destroy(pp_ctx* ctx);
 
 static inline int pp_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

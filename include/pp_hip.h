@@ -49,6 +49,7 @@ typedef struct pp_config {
     int32_t nms_post_max;     /* 300 (<= 1024) */
     float nms_iou_threshold;  /* 0.1  */
     float score_threshold;    /* 0.05 */
+    int32_t max_batch;        /* frames per batched launch of pp_infer_batch (>= 1; 0 is read as 1) */
 } pp_config;
 
 /* Lifetime.  pp_create allocates all device workspace for the configured sizes. */
@@ -99,8 +100,16 @@ int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box, float* di
 int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
                    float* det, int32_t* det_count, int nms_mode, void* stream);
 
-/* Fused frame: voxelise -> mask -> PFN -> (sparse) BEV -> backbone -> head -> post-process, no host sync. */
+/* Fused frame: voxelise -> mask -> PFN -> BEV -> backbone -> head -> post-process, no host sync. */
 int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream);
+
+/* nb <= cfg.max_batch independent frames in ONE pass: the conv/deconv/head launches carry the frame as grid.z
+ * (per-frame InstanceNorm statistics; results identical to nb calls of pp_infer_frame), the small integer
+ * stages run per frame on the same stream.  pts_h / n_h: HOST arrays of nb device pointers / point counts.
+ * det f32[nb][num_classes*nms_post_max][9], det_count i32[nb][PP_DET_COUNT_STRIDE] (total, then per class). */
+#define PP_DET_COUNT_STRIDE (1 + PP_MAX_CLASSES)
+int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int32_t* n_h, int nb, float* det, int32_t* det_count,
+                   int nms_mode, void* stream);
 
 /* Stateless box ops (replace framework/box_torch_ops.py:18-77 and framework/nms.py:6-40,
  * eval/iou.py:438-473). */

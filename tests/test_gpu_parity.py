@@ -363,3 +363,24 @@ def test_postprocess_stage_exact(fw, synth):
     det, cnt = eng.postprocess(torch.full((A,), -20.0).cuda(), torch.from_numpy(box).cuda(), torch.from_numpy(dr).cuda(),
                                torch.from_numpy(mask).cuda())
     assert int(cnt[0]) == 0
+
+
+def test_batched_frames_equal_single_frames(fw, synth):
+    """pp_infer_batch (frame = grid.z of the conv launches, per-frame InstanceNorm statistics) must give the
+    same detections as separate pp_infer_frame calls, including ragged point counts and an empty cloud."""
+    eng_mod = load_pkg("engine")
+    cfg = make_cfg(synth, "nuscene")
+    fw["vg"].VoxelGenerator(cfg)
+    sd = synth.seeded_state_dict(2, cls_bias=-3.0)
+    eng = eng_mod.Engine(cfg, max_batch=3)
+    eng.load_state_dict(sd)
+    clouds = [torch.from_numpy(synth.lidar_cloud("nuscene", seed=10)).cuda(),
+              torch.from_numpy(synth.lidar_cloud("nuscene", seed=11, n_points=5000)).cuda(),
+              torch.zeros((0, 4), dtype=torch.float32).cuda()]
+    det_b, cnt_b = eng.infer_batch(clouds)
+    for i, c in enumerate(clouds):
+        d1, c1 = eng.infer_frame(c)
+        assert np.array_equal(c1.cpu().numpy()[:4], cnt_b[i].cpu().numpy()[:4])
+        k = int(c1[0])
+        np.testing.assert_allclose(det_b[i, :k].cpu().numpy(), d1[:k].cpu().numpy(), rtol=0, atol=1e-5)
+    assert int(cnt_b[2, 0]) == 0
