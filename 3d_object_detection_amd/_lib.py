@@ -60,6 +60,7 @@ PROTOTYPES = {
     "pp_rotated_iou": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, c_p]),
     "pp_profile_begin": (ctypes.c_int, [c_p]),
     "pp_profile_end": (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
+    "pp_dominant_kernel": (ctypes.c_char_p, [c_p]),
     "pp_version": (ctypes.c_int, []),
 }
 

@@ -77,6 +77,7 @@ struct ConvP {
     // batch: blockIdx.z = frame; strides in elements between consecutive frames
     size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
     size_t pre_fs, stat_fs;                        // doubles
+    int nb;                                        // frames (persistent kernels loop over them; others use grid.z)
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -600,28 +601,31 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         const float* ib = il + buf * C::LDS_IN;
         const float* wb = wl + buf * C::LDS_W;
         constexpr int NQ = KC / 4;
-        float draw[2][16], V[16], a[2][MT];
+        // A operands run AD steps ahead of their MFMAs (a step is only 2 MFMAs = 64 cycles; LDS latency is 2-3x that)
+        constexpr int AD = 6;
+        float draw[2][16], V[16], a[AD][MT];
         WN_READ_RAW(draw[0], 0)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[0][i] = wb[aoff + i * 16];
+#define WN_LOAD_A(S)                                                                             \
+    {                                                                                            \
+        constexpr int n4_ = (S) / 16, nx_ = (S) % 16;                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[(S) % AD][i] = wb[(nx_ * KC + n4_ * 4) * C::BMP + aoff + i * 16]; \
+    }
+        pp_steps<0, (AD - 1 < NQ * 16 ? AD - 1 : NQ * 16)>([&](auto S) { WN_LOAD_A(decltype(S)::value) });
         pp_steps<0, NQ * 16>([&](auto S) {
             constexpr int s_ = decltype(S)::value;
-            constexpr int c4 = s_ / 16, xi = s_ % 16, cur = s_ & 1;
+            constexpr int c4 = s_ / 16, xi = s_ % 16;
             if constexpr (xi == 0) {
                 WN_TRANSFORM(V, draw[c4 & 1])
                 if constexpr (c4 + 1 < NQ) WN_READ_RAW(draw[(c4 + 1) & 1], c4 + 1)
             }
-            if constexpr (s_ + 1 < NQ * 16) {
-                constexpr int n4 = (s_ + 1) / 16, nx = (s_ + 1) % 16;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[cur ^ 1][i] = wb[(nx * KC + n4 * 4) * C::BMP + aoff + i * 16];
-            }
+            if constexpr (s_ + AD - 1 < NQ * 16) WN_LOAD_A(s_ + AD - 1)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                acc[i][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], V[xi], acc[i][xi], 0, 0, 0);
+                acc[i][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD][i], V[xi], acc[i][xi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
+#undef WN_LOAD_A
         if (ch + 1 < nchunk && !(p.dbg & 1)) WN_STORE_CHUNK(ch + 1, buf ^ 1)
         __syncthreads();
     }
@@ -713,6 +717,309 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Winograd with the WHOLE transformed weight slab resident in LDS (160 KB per CU on gfx950):
+//   16 positions x CIN x BM floats = 128 KB for CIN*BM = 2048 (CIN 64 x 32 rows, CIN 128 x 16 rows).
+// * persistent workgroups (one per CU, 8 waves): the slab is loaded once per launch, never re-staged
+// * every wavefront is autonomous: it walks (frame, N-tile) items on its own, stages the 6 x 18 raw
+//   patch of its N-tile (16 x 4 output pixels) into a wave-private LDS slot, transforms it in registers
+//   and issues its MFMAs -- no workgroup barrier after the slab load
+// * per chunk of 4 input channels: read raw(c) -> registers, overwrite the slot with raw(c+1) (already
+//   in registers from global), issue the global loads of raw(c+2), then 16*MT*NT MFMAs
+// * InstanceNorm statistics accumulate in registers across a wave's items and are flushed per frame
+// ------------------------------------------------------------------------------------------
+template <int CIN, int MT, int NT>
+struct WresCfg {
+    static constexpr int NW = 8;             // waves per workgroup
+    static constexpr int BM = MT * 16;       // rows shared by all waves
+    static constexpr int KC = 4;
+    static constexpr int NCH = CIN / KC;
+    static constexpr int PWT = 16, PHT = 4;  // output pixels of one N-tile (8 x 2 Winograd tiles)
+    static constexpr int IW = PWT + 2, IH = PHT + 2, HALF = IW / 2;
+    static constexpr int IWP = 20;           // (2*IWP) % 32 == 8: the two tile rows use disjoint banks
+    static constexpr int CS = 144;           // >= IH*IWP, == 16 mod 32
+    static constexpr int NPOS = KC * IH * IW; // 432 raw values per chunk
+    static constexpr int PR = (NPOS + 63) / 64;
+    static constexpr int RAW_FLOATS = KC * CS;             // per N-tile slot
+    static constexpr int U_FLOATS = 16 * CIN * BM;
+    static constexpr int LDS_FLOATS = U_FLOATS + NW * NT * RAW_FLOATS + 2 * NW * CIN; // + per-wave (scale, shift)
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "must fit the 160 KB LDS");
+};
+
+template <int CIN, int MT, int NT>
+__global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
+{
+    using C = WresCfg<CIN, MT, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ul = smem;                                   // [16][CIN][BM] (swizzled when BM == 32)
+    float* rawl = ul + C::U_FLOATS;                     // [NW][NT][KC][CS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    float* scl = rawl + C::NW * NT * C::RAW_FLOATS + wave * 2 * CIN; // wave-private: waves may be on different frames
+    float* shl = scl + CIN;
+
+    const int ncb = p.Cout / C::BM;                     // row blocks
+    const int cb = blockIdx.x % ncb;
+    const int wi = blockIdx.x / ncb, nworkers = gridDim.x / ncb;
+    if (wi >= nworkers) return;
+    const int co0 = cb * C::BM;
+
+    // ---- one-off: resident slab + per-channel (scale, shift) ----
+    {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.w) + (size_t)cb * (C::U_FLOATS / 4);
+        f32x4* d = reinterpret_cast<f32x4*>(ul);
+        for (int e = tid; e < C::U_FLOATS / 4; e += 512) d[e] = g[e];
+    }
+    const int ntx = (p.Wout + C::PWT - 1) / C::PWT, nty = (p.Hout + C::PHT - 1) / C::PHT;
+    const int tiles_per_frame = ntx * nty;
+    const int total = tiles_per_frame * p.nb;
+    const size_t plane = (size_t)p.Hin * p.Win;
+    const size_t out_plane = (size_t)p.Hout * p.Wout;
+
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+    int stat_frame = -1;
+    __syncthreads(); // the resident slab is visible to every wave; no workgroup barrier after this point
+
+    auto flush_stats = [&](int frame) {
+        if (!p.stat_acc || frame < 0) return;
+        double* base = p.stat_acc + (size_t)frame * p.stat_fs + ((size_t)((blockIdx.x * 8 + wave) % NREP) * p.stat_C) * 2;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], q = ssq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o);
+                    q += __shfl_xor(q, o);
+                }
+                if (m == 0) {
+                    const int row = co0 + i * 16 + kq * 4 + r;
+                    atomicAdd(base + (size_t)row * 2, (double)s);
+                    atomicAdd(base + (size_t)row * 2 + 1, (double)q);
+                }
+                ssum[i][r] = 0.f;
+                ssq[i][r] = 0.f;
+            }
+    };
+
+    int cur_pre_frame = -1;
+    const int gw = wi * C::NW + wave, gstride = nworkers * C::NW;
+    // lane constants
+    const int ttx = m & 7, tty = m >> 3;                          // tile inside the N-tile (8 x 2)
+    const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;       // raw patch base of this lane's tile/channel
+    int aoffs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int col = i * 16 + m;
+        aoffs[i] = kq * C::BM + ((C::BM == 32) ? (col ^ ((kq & 1) << 4)) : col);
+    }
+    float* myraw = rawl + wave * NT * C::RAW_FLOATS;
+
+    for (int it0 = gw * NT; it0 < total; it0 += gstride * NT) {
+        // ---- items of this round: NT consecutive N-tiles (same frame whenever possible) ----
+        int fr[NT], oy[NT], ox[NT];
+        bool live[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int item = it0 + j;
+            live[j] = item < total;
+            const int it = live[j] ? item : total - 1;
+            fr[j] = it / tiles_per_frame;
+            const int t = it - fr[j] * tiles_per_frame;
+            oy[j] = (t / ntx) * C::PHT;
+            ox[j] = (t % ntx) * C::PWT;
+        }
+        if (fr[0] != stat_frame) { flush_stats(stat_frame); stat_frame = fr[0]; }
+        // scale/shift of the producer's normalisation for this frame (workgroup-shared; frames change rarely)
+        if (p.pre != PRE_RAW && fr[0] != cur_pre_frame) {
+            for (int c = lane; c < CIN; c += 64) {
+                if (p.pre == PRE_STATS) {
+                    const double* pa = p.pre_acc + (size_t)fr[0] * p.pre_fs;
+                    double s = 0.0, q = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) { s += pa[((size_t)r * CIN + c) * 2]; q += pa[((size_t)r * CIN + c) * 2 + 1]; }
+                    const double mean = s * p.pre_inv_n;
+                    double var = q * p.pre_inv_n - mean * mean;
+                    var = var > 0.0 ? var : 0.0;
+                    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+                    scl[c] = (float)rstd;
+                    shl[c] = (float)(-mean * rstd);
+                } else {
+                    scl[c] = p.pre_scale[c];
+                    shl[c] = p.pre_shift[c];
+                }
+            }
+            cur_pre_frame = fr[0];
+        }
+        // staging map of this round
+        int goff[NT][C::PR], loff[NT][C::PR];
+        unsigned vmask[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            vmask[j] = 0u;
+#pragma unroll
+            for (int r = 0; r < C::PR; ++r) {
+                const int pos = lane + 64 * r;
+                const int c = pos / (C::IH * C::IW);
+                const int q = pos - c * (C::IH * C::IW);
+                const int iy = q / C::IW, ix = q - iy * C::IW;
+                const int gy = oy[j] - 1 + iy, gx = ox[j] - 1 + ix;
+                const bool inb = pos < C::NPOS && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+                goff[j][r] = inb ? (int)((size_t)c * plane) + gy * p.Win + gx : 0;
+                vmask[j] |= (inb ? 1u : 0u) << r;
+                loff[j][r] = pos < C::NPOS ? c * C::CS + iy * C::IWP + (ix & 1) * C::HALF + (ix >> 1) : -1;
+            }
+        }
+        f32x4 acc[MT][NT][16];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[i][j][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float xv[NT][C::PR];
+#define WR_GLOAD(CH)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                             \
+        const float* b_ = p.in + (size_t)fr[j] * p.in_fs + (size_t)((CH) * C::KC) * plane;       \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r) xv[j][r] = b_[goff[j][r]];             \
+    }
+#define WR_LSTORE(CH)                                                                            \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                               \
+        _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                      \
+            if (loff[j][r] >= 0) {                                                               \
+                float v_ = xv[j][r];                                                             \
+                if (p.pre != PRE_RAW) {                                                          \
+                    const int c_ = (CH) * C::KC + (lane + 64 * r) / (C::IH * C::IW);             \
+                    v_ = fmaxf(fmaf(v_, scl[c_], shl[c_]), 0.f);                                 \
+                }                                                                                \
+                myraw[j * C::RAW_FLOATS + loff[j][r]] = ((vmask[j] >> r) & 1u) ? v_ : 0.f;       \
+            }                                                                                    \
+        }
+        WR_GLOAD(0)
+        WR_LSTORE(0)
+        if (C::NCH > 1) WR_GLOAD(1)
+
+        for (int ch = 0; ch < C::NCH; ++ch) {
+            // raw(ch) -> registers, then the slot is free for raw(ch+1)
+            float d[NT][16];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_)
+#pragma unroll
+                    for (int j_ = 0; j_ < 4; ++j_)
+                        d[j][i_ * 4 + j_] = myraw[j * C::RAW_FLOATS + rbase + i_ * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
+            if (ch + 1 < C::NCH) {
+                WR_LSTORE(ch + 1)
+                if (ch + 2 < C::NCH) WR_GLOAD(ch + 2)
+            }
+            float V[NT][16];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float t_[16];
+#pragma unroll
+                for (int j_ = 0; j_ < 4; ++j_) {
+                    t_[0 + j_] = d[j][0 + j_] - d[j][8 + j_];
+                    t_[4 + j_] = d[j][4 + j_] + d[j][8 + j_];
+                    t_[8 + j_] = d[j][8 + j_] - d[j][4 + j_];
+                    t_[12 + j_] = d[j][4 + j_] - d[j][12 + j_];
+                }
+#pragma unroll
+                for (int a_ = 0; a_ < 4; ++a_) {
+                    V[j][a_ * 4 + 0] = t_[a_ * 4 + 0] - t_[a_ * 4 + 2];
+                    V[j][a_ * 4 + 1] = t_[a_ * 4 + 1] + t_[a_ * 4 + 2];
+                    V[j][a_ * 4 + 2] = t_[a_ * 4 + 2] - t_[a_ * 4 + 1];
+                    V[j][a_ * 4 + 3] = t_[a_ * 4 + 1] - t_[a_ * 4 + 3];
+                }
+            }
+            // 16 positions x MT x NT MFMAs, A operands AD steps ahead
+            constexpr int AD = 6;
+            float a[AD][MT];
+            const float* ub = ul + (size_t)(ch * C::KC) * C::BM;
+#define WR_LOAD_A(XI)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) a[(XI) % AD][i] = ub[(XI) * CIN * C::BM + aoffs[i]];
+            pp_steps<0, AD - 1>([&](auto S) { WR_LOAD_A(decltype(S)::value) });
+            pp_steps<0, 16>([&](auto S) {
+                constexpr int xi = decltype(S)::value;
+                if constexpr (xi + AD - 1 < 16) WR_LOAD_A(xi + AD - 1)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xi % AD][i], V[j][xi], acc[i][j][xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#undef WR_LOAD_A
+        }
+#undef WR_GLOAD
+#undef WR_LSTORE
+
+        // ---- epilogue of this round: Y = A^T M A, residual, store, statistics ----
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!live[j]) continue;
+            if (fr[j] != stat_frame) { flush_stats(stat_frame); stat_frame = fr[j]; }
+            const int opx = ox[j] + 2 * ttx, opy = oy[j] + 2 * tty;
+            const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
+            float* gout = p.out + (size_t)fr[j] * p.out_fs;
+            const float* gres = p.res ? p.res + (size_t)fr[j] * p.res_fs : nullptr;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row0 = co0 + i * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t0[4], t1[4];
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_) {
+                        const float m0 = acc[i][j][a_ * 4 + 0][r], m1 = acc[i][j][a_ * 4 + 1][r], m2 = acc[i][j][a_ * 4 + 2][r],
+                                    m3 = acc[i][j][a_ * 4 + 3][r];
+                        t0[a_] = m0 + m1 + m2;
+                        t1[a_] = m1 - m2 - m3;
+                    }
+                    float y00 = t0[0] + t0[1] + t0[2], y01 = t1[0] + t1[1] + t1[2];
+                    float y10 = t0[1] - t0[2] - t0[3], y11 = t1[1] - t1[2] - t1[3];
+                    if (pix_ok) {
+                        const size_t o = (size_t)(row0 + r) * out_plane + (size_t)opy * p.Wout + opx;
+                        const bool two_x = opx + 1 < p.Wout, two_y = opy + 1 < p.Hout;
+                        if (gres) {
+                            if (two_x) {
+                                const float2 r0 = *reinterpret_cast<const float2*>(gres + o);
+                                y00 += r0.x; y01 += r0.y;
+                                if (two_y) { const float2 r1 = *reinterpret_cast<const float2*>(gres + o + p.Wout); y10 += r1.x; y11 += r1.y; }
+                            } else {
+                                y00 += gres[o];
+                                if (two_y) y10 += gres[o + p.Wout];
+                            }
+                        }
+                        if (two_x) {
+                            *reinterpret_cast<float2*>(gout + o) = make_float2(y00, y01);
+                            if (two_y) *reinterpret_cast<float2*>(gout + o + p.Wout) = make_float2(y10, y11);
+                        } else {
+                            gout[o] = y00;
+                            if (two_y) gout[o + p.Wout] = y10;
+                        }
+                        float s_ = y00, q_ = y00 * y00;
+                        if (two_x) { s_ += y01; q_ += y01 * y01; }
+                        if (two_y) { s_ += y10; q_ += y10 * y10; if (two_x) { s_ += y11; q_ += y11 * y11; } }
+                        ssum[i][r] += s_;
+                        ssq[i][r] += q_;
+                    }
+                }
+            }
+        }
+    }
+    flush_stats(stat_frame);
+}
+
 // y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
 // Used for the [conv, norm, relu] head of each block, whose output is both a residual and the
 // input of the next InstanceNorm (pointpillars8_shared.py:133-137).
@@ -786,7 +1093,8 @@ struct Variant { // one compiled tiling of conv_mfma
     int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
     size_t lds;
     char name[48];
-    int wino = 0; // 1: Winograd F(2x2,3x3) image (16 positions instead of 9 taps)
+    int wino = 0; // 1: Winograd F(2x2,3x3) image (16 positions instead of 9 taps); 2: slab-resident persistent Winograd
+    int cin = 0;  // wino == 2: compiled for exactly this Cin
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -813,6 +1121,21 @@ Variant make_wino()
     v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
     v.wino = 1;
     snprintf(v.name, sizeof(v.name), "wino tw%d w%dx%d bx%d kc%d", TWT, WM, WN, BTX, KC);
+    return v;
+}
+
+template <int CIN, int MT, int NT>
+Variant make_wres()
+{
+    using C = WresCfg<CIN, MT, NT>;
+    Variant v;
+    v.kern = wino_res<CIN, MT, NT>;
+    v.bm = C::BM; v.bmp = C::BM; v.pw = C::PWT; v.ph = C::PHT; v.kc = C::KC; v.threads = 512;
+    v.waves = 8; v.pairs = MT * NT * 16;
+    v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    v.wino = 2;
+    v.cin = CIN;
+    snprintf(v.name, sizeof(v.name), "wres c%d m%d n%d", CIN, MT, NT);
     return v;
 }
 
@@ -847,6 +1170,7 @@ struct pp_net {
     float* head_bias = nullptr;
     float* ones = nullptr;
     float* zeros = nullptr;
+    int num_cu = 256;
 };
 
 const int kC[3] = {64, 128, 256};
@@ -878,7 +1202,7 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu)
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0)
 {
     if (kind == 2) {
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 5, 1, 16, EPI_HEAD>());
@@ -907,6 +1231,8 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu)
         menu.push_back(make_wino<2, 1, 4, 2, 8>());  // 8x32 px (2x8-tile N-tiles), 32 rows
         menu.push_back(make_wino<8, 1, 4, 1, 4>());
         menu.push_back(make_wino<4, 1, 4, 2, 4>());
+        if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
+        if (cin == 128) menu.push_back(make_wres<128, 1, 1>()); // 128 KB slab: 128 ch x 16 rows
     }
 }
 
@@ -921,7 +1247,7 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
     return cost;
 }
 
-bool variant_ok(const Variant& v, int rows) { return v.bm <= ((rows + 63) / 64) * 64; }
+bool variant_ok(const Variant& v, int rows) { return v.wino == 2 ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
 
 Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
 {
@@ -976,7 +1302,7 @@ int pack_layer(pp_ctx* ctx, Layer& L)
     }
     L.rows = rows;
     int taps_eff = taps;
-    if (v.wino) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
+    if (v.wino) { // (1 and 2) U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         std::vector<float> u((size_t)rows * L.cin * 16);
         for (size_t rc = 0; rc < (size_t)rows * L.cin; ++rc) {
@@ -989,6 +1315,21 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
         rowsW.swap(u);
         taps_eff = 16;
+    }
+    if (v.wino == 2) { // [row block][position][cin][BM], 16-float halves swapped on odd channels when BM == 32
+        const int nb_ = rows / v.bm;
+        std::vector<float> pk2((size_t)nb_ * 16 * L.cin * v.bm, 0.f);
+        for (int b = 0; b < nb_; ++b)
+            for (int x = 0; x < 16; ++x)
+                for (int c = 0; c < L.cin; ++c)
+                    for (int mm = 0; mm < v.bm; ++mm) {
+                        const int col = (v.bm == 32) ? (mm ^ ((c & 1) << 4)) : mm;
+                        pk2[(((size_t)b * 16 + x) * L.cin + c) * v.bm + col] = rowsW[((size_t)(b * v.bm + mm) * L.cin + c) * 16 + x];
+                    }
+        if (L.w) (void)hipFree(L.w);
+        PP_HIP(hipMalloc((void**)&L.w, pk2.size() * sizeof(float)));
+        PP_HIP(hipMemcpy(L.w, pk2.data(), pk2.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
     }
     const int nblk = pp_div_up(rows, v.bm), nchunk = L.cin / v.kc;
     std::vector<float> pk((size_t)nblk * nchunk * taps_eff * v.kc * v.bmp, 0.f); // LDS image incl. row padding
@@ -1038,6 +1379,13 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     }
     const Variant& v = L.var;
     dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm), B);
+    p.nb = B;
+    if (v.wino == 2) { // persistent: one workgroup per CU, a multiple of the row-block count
+        const int ncb = L.rows / v.bm;
+        int g = (net->num_cu / ncb) * ncb;
+        if (g < ncb) g = ncb;
+        grid = dim3(g, 1, 1);
+    }
     const bool tag = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
     if (tag) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -1114,7 +1462,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d b%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind,
              ctx->max_batch < 4 ? ctx->max_batch : 4);
     std::vector<Variant> menu;
-    layer_menu(L.kind, L.stride, L.up, menu);
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
@@ -1170,6 +1518,10 @@ int pp_net_create(pp_ctx* ctx)
     pp_net* net = new pp_net();
     ctx->net = net;
     const int H = ctx->H, W = ctx->W;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) net->num_cu = prop.multiProcessorCount;
+    }
     for (int l = 0; l < 3; ++l)
         for (int b = 0; b < 4; ++b)
             PP_HIP(hipMalloc((void**)&net->buf[l][b], (size_t)ctx->max_batch * kC[l] * ((H >> l) + 1) * ((W >> l) + 1) * sizeof(float)));
@@ -1511,4 +1863,13 @@ extern "C" int pp_profile_end(pp_ctx* ctx, double* avg_ms, int32_t* launches, do
     *flops = ctx->prof_flops;
     ctx->prof_used = 0;
     return 0;
+}
+
+extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
+{
+    if (!ctx || !ctx->net) return "";
+    pp_net* net = (pp_net*)ctx->net;
+    for (const Layer& L : net->layers)
+        if (L.kind == 0 && L.level == 0 && L.stride == 1) return L.var.name;
+    return "";
 }

@@ -268,6 +268,9 @@ class Engine:
                        self.ctx, "pp_infer_batch")
         return det, cnt
 
+    def dominant_kernel(self):
+        return self.lib.pp_dominant_kernel(self.ctx).decode()
+
     def profile_begin(self):
         _lib.check(self.lib.pp_profile_begin(self.ctx), self.ctx, "pp_profile_begin")
 

@@ -86,11 +86,11 @@ def cpu_baseline(synth, n_frames=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="eight_20cm")
     ap.add_argument("--cls-bias", type=float, default=None, help="'trained-like' head bias (e.g. -4.6); default random init")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight per GPU: independent frames run on separate HIP streams (one pp_ctx each) so one "
                          "frame's kernel tails / small kernels overlap another frame's MFMA work")
     ap.add_argument("--batch", type=int, default=4,
@@ -190,7 +190,7 @@ def main():
                        "cls_bias": args.cls_bias, "mean_detections": float(cnt_h[:, :, 0].float().mean())},
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma<3,1,16,...> (3x3 s1, 64->64 @ H/2 x W/2)",
+        out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{NB} frames, tiling '{eng.dominant_kernel()}'",
                            "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "avg_launch_ms": round(k_ms, 5), "launches": k_n, "flops_per_launch": k_flops}

@@ -128,6 +128,8 @@ int pp_rotated_iou(const float* boxes_a /*[n,5]*/, const float* boxes_b /*[m,5]*
  * the number of launches seen and the algorithmic FLOPs of one launch (2*H*W*Cin*Cout*9). */
 int pp_profile_begin(pp_ctx* ctx);
 int pp_profile_end(pp_ctx* ctx, double* avg_ms_h, int32_t* launches_h, double* flops_per_launch_h);
+/* name of the tiling the autotuner chose for that dominant layer (static string owned by ctx) */
+const char* pp_dominant_kernel(pp_ctx* ctx);
 int pp_version(void);
 
 #ifdef __cplusplus
