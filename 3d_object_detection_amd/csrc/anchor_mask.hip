@@ -95,20 +95,25 @@ __global__ void __launch_bounds__(256) mask_lookup_full(const int32_t* __restric
 extern "C" int pp_anchor_mask(pp_ctx* ctx, const int32_t* coors, const int32_t* num_pillars, uint8_t* mask, void* stream_)
 {
     if (!ctx) return PP_E_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
+    return pp_anchor_mask_slot(ctx, 0, coors, num_pillars, mask, (hipStream_t)stream_);
+}
+
+int pp_anchor_mask_slot(pp_ctx* ctx, int si, const int32_t* coors, const int32_t* num_pillars, uint8_t* mask, hipStream_t stream)
+{
+    pp_slot& S = ctx->slot[si];
     if (!coors || !num_pillars || !mask) return pp_fail(ctx, PP_E_ARG, "pp_anchor_mask: null pointer");
     if (ctx->A == 0) return pp_fail(ctx, PP_E_STATE, "pp_anchor_mask: call pp_set_anchors first");
     const int gx = ctx->gx, gy = ctx->gy;
-    PP_HIP(hipMemsetAsync(ctx->occ, 0, (size_t)gx * gy * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(occ_mark, dim3(pp_div_up(ctx->cfg.max_voxels, 256)), dim3(256), 0, stream, coors, num_pillars, gy, ctx->occ);
-    hipLaunchKernelGGL(scan_rows, dim3(pp_div_up(gx, 4)), dim3(256), 0, stream, ctx->occ, gx, gy);
-    hipLaunchKernelGGL(scan_cols, dim3(pp_div_up(gy, 64)), dim3(1024), 0, stream, ctx->occ, gx, gy);
+    PP_HIP(hipMemsetAsync(S.occ, 0, (size_t)gx * gy * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(occ_mark, dim3(pp_div_up(ctx->cfg.max_voxels, 256)), dim3(256), 0, stream, coors, num_pillars, gy, S.occ);
+    hipLaunchKernelGGL(scan_rows, dim3(pp_div_up(gx, 4)), dim3(256), 0, stream, S.occ, gx, gy);
+    hipLaunchKernelGGL(scan_cols, dim3(pp_div_up(gy, 64)), dim3(1024), 0, stream, S.occ, gx, gy);
     if (ctx->rect_separable) {
         int types = (int)(ctx->A / ((int64_t)ctx->H * ctx->W));
-        hipLaunchKernelGGL(mask_lookup_sep, dim3(pp_div_up(ctx->A, 256)), dim3(256), 0, stream, ctx->occ, gy, ctx->H, ctx->W,
+        hipLaunchKernelGGL(mask_lookup_sep, dim3(pp_div_up(ctx->A, 256)), dim3(256), 0, stream, S.occ, gy, ctx->H, ctx->W,
                            types, ctx->rect_x, ctx->rect_y, mask);
     } else {
-        hipLaunchKernelGGL(mask_lookup_full, dim3(pp_div_up(ctx->A, 256)), dim3(256), 0, stream, ctx->occ, gy, ctx->A,
+        hipLaunchKernelGGL(mask_lookup_full, dim3(pp_div_up(ctx->A, 256)), dim3(256), 0, stream, S.occ, gy, ctx->A,
                            (const int4*)ctx->rects, mask);
     }
     PP_HIP(hipGetLastError());

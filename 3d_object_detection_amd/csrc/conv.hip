@@ -435,7 +435,9 @@ struct WinoCfg {
     }
     static constexpr int CS = cs();
     static constexpr int BM = WM * MT * 16;
-    static constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
+    // A image row = [wm][m 0..15][M-tile 0/1]: one ds_read_b64 fetches a lane's two A operands; a 32-float row needs no
+    // padding (kq and kq+1 fall on opposite 32-bank halves of the 64-bank b64 access), a 64-float row is padded by 32
+    static constexpr int BMP = (BM == 32) ? 32 : BM + 32;
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int NPOS = IH * IW;
     static constexpr int PR = (NPOS + THREADS - 1) / THREADS;
@@ -503,6 +505,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         }
     }
 
+    // byte offsets inside a channel plane (buffer loads: SGPR base + 32-bit VGPR offset, no 64-bit address math)
     int goff[C::PR], loff[C::PR];
     unsigned vmask = 0u;
 #pragma unroll
@@ -511,17 +514,23 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         const int iy = pos / C::IW, ix = pos - iy * C::IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool inb = pos < C::NPOS && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-        goff[r] = inb ? gy * p.Win + gx : 0;
+        goff[r] = inb ? (gy * p.Win + gx) * 4 : 0;
         vmask |= (inb ? 1u : 0u) << r;
         loff[r] = pos < C::NPOS ? iy * C::IWP + (ix & 1) * C::HALF + (ix >> 1) : -1;
     }
+    // interior patches (the vast majority) need no zero-padding select at all: workgroup-uniform fast path
+    const bool all_in = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::IH <= p.Hin) && (ix0 + C::IW <= p.Win);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gin), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned plane_b = (unsigned)(p.Hin * p.Win) * 4u;
+    const unsigned wbase_b = (unsigned)((size_t)blockIdx.y * (p.Cin / KC) * C::W4 * 16);
 
     // this lane's tile: block-local tile coords -> top-left output pixel and raw-patch base
     const int btx = wn % BTX, bty = wn / BTX;
     const int ttx = btx * TWT + (m % TWT), tty = bty * C::THT + (m / TWT);
     const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
     const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
-    const int aoff = kq * C::BMP + wm * MT * 16 + m;
+    const int aoff = kq * C::BMP + wm * 32 + m * 2; // float2 {M-tile 0, M-tile 1}
 
     f32x4 acc[MT][16];
 #pragma unroll
@@ -531,32 +540,40 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 
     const size_t in_plane = (size_t)p.Hin * p.Win;
     const int nchunk = p.Cin / KC;
-    const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(p.w) + (size_t)blockIdx.y * nchunk * C::W4;
 
     float xv[C::PR][KC];
     f32x4 wv[C::WR];
 
 #define WN_LOAD_CHUNK(CH)                                                                        \
     {                                                                                            \
-        const float* base_ = gin + (size_t)((CH) * KC) * in_plane;                              \
+        const unsigned cb_ = (unsigned)((CH) * KC) * plane_b;                                    \
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
-            _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
-        const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
+            _Pragma("unroll") for (int c = 0; c < KC; ++c)                                       \
+                xv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[r], cb_ + (unsigned)c * plane_b, 0)); \
+        const unsigned wb_ = wbase_b + (unsigned)(CH) * (C::W4 * 16);                            \
         _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
             const int e_ = tid + r * C::THREADS;                                                 \
-            wv[r] = g_[e_ < C::W4 ? e_ : C::W4 - 1];                                             \
+            wv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (e_ < C::W4 ? e_ : C::W4 - 1) * 16, wb_, 0)); \
         }                                                                                        \
     }
 #define WN_STORE_CHUNK(CH, BUF)                                                                  \
     {                                                                                            \
         float* ib_ = il + (BUF) * C::LDS_IN;                                                     \
         const int c0_ = (CH) * KC;                                                               \
+        float sc_[KC], sh_[KC];                                                                  \
+        if (p.pre != PRE_RAW) {                                                                  \
+            _Pragma("unroll") for (int c = 0; c < KC; c += 4) {                                  \
+                const f32x4 a_ = *reinterpret_cast<const f32x4*>(scl + c0_ + c);                 \
+                const f32x4 b_ = *reinterpret_cast<const f32x4*>(shl + c0_ + c);                 \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) { sc_[c + q] = a_[q]; sh_[c + q] = b_[q]; } \
+            }                                                                                    \
+        }                                                                                        \
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                      \
             if (loff[r] >= 0) {                                                                  \
-                const bool inb_ = (vmask >> r) & 1u;                                             \
+                const bool inb_ = all_in || ((vmask >> r) & 1u);                                 \
                 _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                 \
                     float v_ = xv[r][c];                                                         \
-                    if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, scl[c0_ + c], shl[c0_ + c]), 0.f); \
+                    if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, sc_[c], sh_[c]), 0.f);             \
                     ib_[c * C::CS + loff[r]] = inb_ ? v_ : 0.f;                                  \
                 }                                                                                \
             }                                                                                    \
@@ -603,12 +620,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         constexpr int NQ = KC / 4;
         // A operands run AD steps ahead of their MFMAs (a step is only 2 MFMAs = 64 cycles; LDS latency is 2-3x that)
         constexpr int AD = 6;
-        float draw[2][16], V[16], a[AD][MT];
+        float draw[2][16], V[16];
+        float2 a[AD];
         WN_READ_RAW(draw[0], 0)
 #define WN_LOAD_A(S)                                                                             \
     {                                                                                            \
         constexpr int n4_ = (S) / 16, nx_ = (S) % 16;                                            \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[(S) % AD][i] = wb[(nx_ * KC + n4_ * 4) * C::BMP + aoff + i * 16]; \
+        a[(S) % AD] = *reinterpret_cast<const float2*>(wb + (nx_ * KC + n4_ * 4) * C::BMP + aoff); \
     }
         pp_steps<0, (AD - 1 < NQ * 16 ? AD - 1 : NQ * 16)>([&](auto S) { WN_LOAD_A(decltype(S)::value) });
         pp_steps<0, NQ * 16>([&](auto S) {
@@ -620,9 +638,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             }
             if constexpr (s_ + AD - 1 < NQ * 16) WN_LOAD_A(s_ + AD - 1)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                acc[i][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD][i], V[xi], acc[i][xi], 0, 0, 0);
+            acc[0][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].x, V[xi], acc[0][xi], 0, 0, 0);
+            acc[1][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].y, V[xi], acc[1][xi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
 #undef WN_LOAD_A
@@ -1020,6 +1037,222 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
     flush_stats(stat_frame);
 }
 
+// ------------------------------------------------------------------------------------------
+// 1x1 contractions (the three ConvTranspose(k = s) upsamplers and the shared head) as a persistent,
+// barrier-free GEMM:  D[rows, pixel] = W[rows, K] * relu(norm(X[K, pixel]))
+// * the [K][BM] weight slab of the workgroup's row block stays in LDS for the whole launch
+//   (head: 320 x 96, deconv3: 256 x 128 -> up to 147 KB of the 160 KB)
+// * activations never touch LDS: lane (pixel m, channel c+kq) loads its B operand straight from
+//   global memory into a 4-step register ring, applies the producer's normalisation + ReLU in
+//   registers, and feeds the MFMAs -- every wave streams on its own, no workgroup barrier
+// * pixels are flattened (a 1x1 conv has no neighbourhood), N-tile = 16 consecutive pixels
+// ------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI>
+__global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
+{
+    constexpr int BM = MT * 16;
+    constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
+    constexpr int PD = 6; // B-operand ring depth (steps in flight)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                         // [K][BMP]
+    const int K = p.Cin;
+    float* sc_all = wl + (size_t)K * BMP;     // [8 waves][2][K]  wave-private (scale, shift)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    float* scl = sc_all + (size_t)wave * 2 * K;
+    float* shl = scl + K;
+
+    const int ncb = (p.Cout + BM - 1) / BM;
+    const int cb = blockIdx.x % ncb;
+    const int wi = blockIdx.x / ncb, nworkers = gridDim.x / ncb;
+    if (wi >= nworkers) return;
+    const int co0 = cb * BM;
+    {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.w) + (size_t)cb * ((size_t)K * BMP / 4);
+        f32x4* d = reinterpret_cast<f32x4*>(wl);
+        for (int e = tid; e < K * BMP / 4; e += 512) d[e] = g[e];
+    }
+    __syncthreads(); // the only workgroup barrier
+
+    const int HW = p.Hout * p.Wout;
+    const int items_per_frame = (HW + NT * 16 - 1) / (NT * 16);
+    const int total = items_per_frame * p.nb;
+    const size_t plane = (size_t)HW;
+    const int gw = wi * 8 + wave, gstride = nworkers * 8;
+
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+    int stat_frame = -1, pre_frame = -1;
+    auto flush_stats = [&](int frame) {
+        if (EPI == EPI_HEAD || !p.stat_acc || frame < 0) return;
+        double* base = p.stat_acc + (size_t)frame * p.stat_fs + ((size_t)((blockIdx.x * 8 + wave) % NREP) * p.stat_C) * 2;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[i][r], q = ssq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o);
+                    q += __shfl_xor(q, o);
+                }
+                const int row = co0 + i * 16 + kq * 4 + r;
+                int ch = row;
+                bool lead = (m == 0);
+                if (EPI == EPI_UP2) { ch = row >> 2; lead = lead && r == 0; }
+                if (EPI == EPI_UP4) { ch = row >> 4; lead = lead && r == 0; }
+                if (lead && row < p.Cout) {
+                    atomicAdd(base + (size_t)ch * 2, (double)s);
+                    atomicAdd(base + (size_t)ch * 2 + 1, (double)q);
+                }
+                ssum[i][r] = 0.f;
+                ssq[i][r] = 0.f;
+            }
+    };
+
+    const int aoff = kq * BMP + m;
+    for (int item = gw; item < total; item += gstride) {
+        const int fr = item / items_per_frame;
+        const int pix0 = (item - fr * items_per_frame) * (NT * 16);
+        if (fr != stat_frame) { flush_stats(stat_frame); stat_frame = fr; }
+        if (p.pre != PRE_RAW && fr != pre_frame) {
+            for (int c = lane; c < K; c += 64) {
+                if (p.pre == PRE_STATS) {
+                    const double* pa = p.pre_acc + (size_t)fr * p.pre_fs;
+                    double s = 0.0, q = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) { s += pa[((size_t)r * K + c) * 2]; q += pa[((size_t)r * K + c) * 2 + 1]; }
+                    const double mean = s * p.pre_inv_n;
+                    double var = q * p.pre_inv_n - mean * mean;
+                    var = var > 0.0 ? var : 0.0;
+                    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+                    scl[c] = (float)rstd;
+                    shl[c] = (float)(-mean * rstd);
+                } else {
+                    scl[c] = p.pre_scale[c];
+                    shl[c] = p.pre_shift[c];
+                }
+            }
+            pre_frame = fr;
+        }
+        // N-tile j of this item = pixels {pix0 + 4m + j}: one dwordx4 per lane and step feeds all four tiles
+        static_assert(NT == 4, "gemm1x1 is written for 4 interleaved N-tiles");
+        const float* gin = p.in + (size_t)fr * p.in_fs + (size_t)kq * plane;
+        const int pxb = pix0 + 4 * m;       // first of this lane's 4 pixels (HW % 4 == 0: all four valid or none)
+        const bool pok = pxb < HW;
+        const int pof = pok ? pxb : 0;
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        f32x4 bq[PD];
+        const int nsteps = K / 4;
+#define G1_LOADB(S, SLOT) bq[SLOT] = *reinterpret_cast<const f32x4*>(gin + (size_t)(S) * 4 * plane + pof);
+#pragma unroll
+        for (int s0 = 0; s0 < PD - 1; ++s0)
+            if (s0 < nsteps) G1_LOADB(s0, s0)
+        for (int sb = 0; sb < nsteps; sb += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int st = sb + u;
+                if (st < nsteps) {
+                    if (st + PD - 1 < nsteps) G1_LOADB(st + PD - 1, (u + PD - 1) % PD)
+                    float a[MT], b[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) a[i] = wl[(size_t)st * 4 * BMP + aoff + i * 16];
+                    if (p.pre != PRE_RAW) {
+                        const float sc = scl[st * 4 + kq], sh = shl[st * 4 + kq];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) b[j] = fmaxf(fmaf(bq[u][j], sc, sh), 0.f);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) b[j] = bq[u][j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+#undef G1_LOADB
+
+        // ---- epilogue of this item (lane m owns pixels pxb .. pxb+3, one per N-tile) ----
+        float* gout = p.out + (size_t)fr * p.out_fs;
+        float* gbox = p.out_box ? p.out_box + (size_t)fr * p.box_fs : nullptr;
+        float* gdir = p.out_dir ? p.out_dir + (size_t)fr * p.dir_fs : nullptr;
+        if (pok) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row0 = co0 + i * 16 + kq * 4;
+                if (row0 >= p.Cout) continue;
+                if (EPI == EPI_PLAIN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 x = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                        *reinterpret_cast<f32x4*>(gout + (size_t)(row0 + r) * plane + pxb) = x;
+                        ssum[i][r] += (x[0] + x[1]) + (x[2] + x[3]);
+                        ssq[i][r] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                    }
+                } else if (EPI == EPI_UP2) {
+                    const int co = row0 >> 2;
+                    const size_t W2 = (size_t)p.Wout * 2;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int px = pxb + j;
+                        const int y = px / p.Wout, xx = px - y * p.Wout;
+                        const f32x4 v = acc[i][j];
+                        float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * y) * W2 + 2 * xx;
+                        *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+                        *reinterpret_cast<float2*>(o + W2) = make_float2(v[2], v[3]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+                    }
+                } else if (EPI == EPI_UP4) {
+                    const int co = row0 >> 4, dy = (row0 >> 2) & 3;
+                    const size_t W4o = (size_t)p.Wout * 4;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int px = pxb + j;
+                        const int y = px / p.Wout, xx = px - y * p.Wout;
+                        const f32x4 v = acc[i][j];
+                        float* o = gout + (size_t)co * plane * 16 + (size_t)(4 * y + dy) * W4o + 4 * xx;
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = row0 + r;
+                        if (row >= p.n_rows) continue;
+                        const float bias = p.bias[row];
+                        if (row < p.n_cls) {
+                            const f32x4 x = (f32x4){acc[i][0][r] + bias, acc[i][1][r] + bias, acc[i][2][r] + bias, acc[i][3][r] + bias};
+                            *reinterpret_cast<f32x4*>(gout + (size_t)row * plane + pxb) = x;
+                        } else if (row < p.n_cls + p.n_box) {
+                            const int q = row - p.n_cls, a_ = q / 7, k = q - a_ * 7;
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) gbox[((size_t)a_ * plane + pxb + j) * 7 + k] = acc[i][j][r] + bias;
+                        } else {
+                            const int q = row - p.n_cls - p.n_box, a_ = q >> 1, k = q & 1;
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) gdir[((size_t)a_ * plane + pxb + j) * 2 + k] = acc[i][j][r] + bias;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush_stats(stat_frame);
+}
+
 // y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
 // Used for the [conv, norm, relu] head of each block, whose output is both a residual and the
 // input of the next InstanceNorm (pointpillars8_shared.py:133-137).
@@ -1093,7 +1326,7 @@ struct Variant { // one compiled tiling of conv_mfma
     int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
     size_t lds;
     char name[48];
-    int wino = 0; // 1: Winograd F(2x2,3x3) image (16 positions instead of 9 taps); 2: slab-resident persistent Winograd
+    int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
     int cin = 0;  // wino == 2: compiled for exactly this Cin
 };
 
@@ -1136,6 +1369,19 @@ Variant make_wres()
     v.wino = 2;
     v.cin = CIN;
     snprintf(v.name, sizeof(v.name), "wres c%d m%d n%d", CIN, MT, NT);
+    return v;
+}
+
+template <int MT, int NT, int EPI>
+Variant make_g1()
+{
+    Variant v;
+    v.kern = gemm1x1<MT, NT, EPI>;
+    v.bm = MT * 16; v.bmp = v.bm + ((v.bm % 32 == 0) ? 16 : 0); v.pw = NT * 16; v.ph = 1; v.kc = 4; v.threads = 512;
+    v.waves = 8; v.pairs = MT * NT;
+    v.lds = 0; // depends on K: set per layer
+    v.wino = 3;
+    snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d", MT, NT, EPI);
     return v;
 }
 
@@ -1205,6 +1451,8 @@ void conv_menu(std::vector<Variant>& m)
 void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0)
 {
     if (kind == 2) {
+        menu.push_back(make_g1<6, 4, EPI_HEAD>());
+        menu.push_back(make_g1<3, 4, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 5, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 2, 2, 3, 5, 1, 16, EPI_HEAD>());
@@ -1212,9 +1460,9 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         menu.push_back(make_variant<1, 1, 8, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 8, 2, 2, 3, 4, 2, 16, EPI_HEAD>());
     } else if (kind == 1) {
-        if (up == 1) conv_menu<1, 1, 16, EPI_PLAIN>(menu);
-        else if (up == 2) conv_menu<1, 1, 16, EPI_UP2>(menu);
-        else conv_menu<1, 1, 16, EPI_UP4>(menu);
+        if (up == 1) { conv_menu<1, 1, 16, EPI_PLAIN>(menu); menu.push_back(make_g1<4, 4, EPI_PLAIN>()); menu.push_back(make_g1<2, 4, EPI_PLAIN>()); }
+        else if (up == 2) { conv_menu<1, 1, 16, EPI_UP2>(menu); menu.push_back(make_g1<4, 4, EPI_UP2>()); menu.push_back(make_g1<8, 4, EPI_UP2>()); }
+        else { conv_menu<1, 1, 16, EPI_UP4>(menu); menu.push_back(make_g1<4, 4, EPI_UP4>()); menu.push_back(make_g1<8, 4, EPI_UP4>()); }
     } else if (stride == 2) {
         conv_menu<3, 2, 8, EPI_PLAIN>(menu);
     } else {
@@ -1248,6 +1496,8 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
 }
 
 bool variant_ok(const Variant& v, int rows) { return v.wino == 2 ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
+// LDS bytes of a persistent 1x1 GEMM for a given K
+size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
 Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
 {
@@ -1256,7 +1506,7 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
     double best = 1e30;
     Variant bv = menu[0];
     for (const Variant& v : menu) {
-        if (!variant_ok(v, rows)) continue;
+        if (!variant_ok(v, rows) || v.wino >= 2) continue; // persistent kernels are only chosen by measurement
         const double c = model_cost(v, rows, Hout, Wout);
         if (c < best) { best = c; bv = v; }
     }
@@ -1302,7 +1552,7 @@ int pack_layer(pp_ctx* ctx, Layer& L)
     }
     L.rows = rows;
     int taps_eff = taps;
-    if (v.wino) { // (1 and 2) U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
+    if (v.wino == 1 || v.wino == 2) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         std::vector<float> u((size_t)rows * L.cin * 16);
         for (size_t rc = 0; rc < (size_t)rows * L.cin; ++rc) {
@@ -1315,6 +1565,20 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
         rowsW.swap(u);
         taps_eff = 16;
+    }
+    if (v.wino == 3) { // [row block][K][BMP]
+        const int nb_ = pp_div_up(rows, v.bm);
+        std::vector<float> pk3((size_t)nb_ * L.cin * v.bmp, 0.f);
+        for (int b = 0; b < nb_; ++b)
+            for (int c = 0; c < L.cin; ++c)
+                for (int mm = 0; mm < v.bm; ++mm) {
+                    const int row = b * v.bm + mm;
+                    if (row < rows) pk3[((size_t)b * L.cin + c) * v.bmp + mm] = rowsW[(size_t)row * L.cin + c];
+                }
+        if (L.w) (void)hipFree(L.w);
+        PP_HIP(hipMalloc((void**)&L.w, pk3.size() * sizeof(float)));
+        PP_HIP(hipMemcpy(L.w, pk3.data(), pk3.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
     }
     if (v.wino == 2) { // [row block][position][cin][BM], 16-float halves swapped on odd channels when BM == 32
         const int nb_ = rows / v.bm;
@@ -1340,7 +1604,9 @@ int pack_layer(pp_ctx* ctx, Layer& L)
                     for (int mm = 0; mm < v.bm; ++mm) {
                         const int row = b * v.bm + mm;
                         if (row >= rows) continue;
-                        pk[((((size_t)b * nchunk + ch) * taps_eff + t) * v.kc + k) * v.bmp + mm] =
+                        // Winograd image: row = [wm][m][M-tile] so a lane's two A operands are adjacent (ds_read_b64)
+                        const int col = (v.wino == 1) ? ((mm >> 5) * 32 + (mm & 15) * 2 + ((mm >> 4) & 1)) : mm;
+                        pk[((((size_t)b * nchunk + ch) * taps_eff + t) * v.kc + k) * v.bmp + col] =
                             rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps_eff + t];
                     }
     if (L.w) (void)hipFree(L.w);
@@ -1380,8 +1646,10 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     const Variant& v = L.var;
     dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm), B);
     p.nb = B;
-    if (v.wino == 2) { // persistent: one workgroup per CU, a multiple of the row-block count
-        const int ncb = L.rows / v.bm;
+    size_t lds_bytes = v.lds;
+    if (v.wino == 3) lds_bytes = g1_lds(v, L.cin);
+    if (v.wino == 2 || v.wino == 3) { // persistent: one workgroup per CU, a multiple of the row-block count
+        const int ncb = pp_div_up(L.rows, v.bm);
         int g = (net->num_cu / ncb) * ncb;
         if (g < ncb) g = ncb;
         grid = dim3(g, 1, 1);
@@ -1398,7 +1666,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0 * B;
         PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used], stream));
     }
-    hipLaunchKernelGGL(v.kern, grid, dim3(v.threads), v.lds, stream, p);
+    hipLaunchKernelGGL(v.kern, grid, dim3(v.threads), lds_bytes, stream, p);
     if (tag) {
         PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], stream));
         ctx->prof_used += 2;
@@ -1484,9 +1752,10 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     Variant bv = L.var;
     for (const Variant& v : menu) {
         if (!variant_ok(v, rows)) continue;
-        if (v.lds > 160 * 1024) continue;
+        const size_t need = (v.wino == 3) ? g1_lds(v, L.cin) : v.lds;
+        if (need > 160 * 1024) continue;
         L.var = v;
-        PP_HIP(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        PP_HIP(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         int rc = pack_layer(ctx, L);
         if (rc) return rc;
         float ms = 0.f;
@@ -1646,7 +1915,8 @@ int pp_net_commit(pp_ctx* ctx)
                 rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose);
                 if (rc) { (void)hipFree(tin); (void)hipFree(tout); return rc; }
             }
-            PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
+            PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(L.var.wino == 3 ? g1_lds(L.var, L.cin) : L.var.lds)));
             rc = pack_layer(ctx, L);
             if (rc) return rc;
         }

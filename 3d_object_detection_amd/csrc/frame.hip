@@ -20,23 +20,40 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
     const size_t plane = (size_t)ctx->gx * ctx->gy * 64;
     const size_t A = (size_t)ctx->A;
     int rc;
+    // Fork: the integer stages of the nb frames are independent and latency-bound, so frames 1.. run on the
+    // slots' internal streams concurrently with frame 0 (caller's stream); all join before the shared conv launches.
+    if (nb > 1) PP_HIP(hipEventRecord(ctx->ev_fork, stream));
     for (int b = 0; b < nb; ++b) {
+        hipStream_t st = (b == 0) ? stream : ctx->slot[b].stream;
+        if (b > 0) PP_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
         float* vox = ctx->f_voxels + b * vs;
         int32_t* coors = ctx->f_coors + b * mv * 3;
         int32_t* npts = ctx->f_npts + b * mv;
         int32_t* num = ctx->f_num + b * 4;
         float* feat = ctx->f_feat + b * mv * 64;
-        if ((rc = pp_voxelize(ctx, pts_h[b], n_h[b], c.num_point_features, vox, coors, npts, num, stream))) return rc;
-        if ((rc = pp_anchor_mask(ctx, coors, num, ctx->f_mask + b * A, stream))) return rc;
-        if ((rc = pp_pfn(ctx, vox, coors, npts, num, feat, stream))) return rc;
-        if ((rc = pp_scatter(ctx, feat, coors, num, ctx->f_canvas + b * plane, stream))) return rc;
+        if ((rc = pp_voxelize_slot(ctx, b, pts_h[b], n_h[b], c.num_point_features, vox, coors, npts, num, st))) return rc;
+        if ((rc = pp_anchor_mask_slot(ctx, b, coors, num, ctx->f_mask + b * A, st))) return rc;
+        if ((rc = pp_pfn(ctx, vox, coors, npts, num, feat, st))) return rc;
+        if ((rc = pp_scatter(ctx, feat, coors, num, ctx->f_canvas + b * plane, st))) return rc;
+        if (b > 0) {
+            PP_HIP(hipEventRecord(ctx->slot[b].ev_pre, st));
+            PP_HIP(hipStreamWaitEvent(stream, ctx->slot[b].ev_pre, 0));
+        }
     }
     if ((rc = pp_run_backbone(ctx, ctx->f_canvas, nb, stream))) return rc;
     if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
     const size_t rows = (size_t)c.num_classes * c.nms_post_max;
-    for (int b = 0; b < nb; ++b)
-        if ((rc = pp_postprocess(ctx, ctx->f_cls + b * A, ctx->f_box + b * A * 7, ctx->f_dir + b * A * 2, ctx->f_mask + b * A,
-                                 det + b * rows * 9, det_count + b * PP_DET_COUNT_STRIDE, nms_mode, stream))) return rc;
+    if (nb > 1) PP_HIP(hipEventRecord(ctx->ev_mid, stream));
+    for (int b = 0; b < nb; ++b) {
+        hipStream_t st = (b == 0) ? stream : ctx->slot[b].stream;
+        if (b > 0) PP_HIP(hipStreamWaitEvent(st, ctx->ev_mid, 0));
+        if ((rc = pp_postprocess_slot(ctx, b, ctx->f_cls + b * A, ctx->f_box + b * A * 7, ctx->f_dir + b * A * 2, ctx->f_mask + b * A,
+                                      det + b * rows * 9, det_count + b * PP_DET_COUNT_STRIDE, nms_mode, st))) return rc;
+        if (b > 0) {
+            PP_HIP(hipEventRecord(ctx->slot[b].ev_post, st));
+            PP_HIP(hipStreamWaitEvent(stream, ctx->slot[b].ev_post, 0));
+        }
+    }
     return 0;
 }
 

@@ -524,10 +524,10 @@ int shift_for(uint32_t thr_bits)
 
 } // namespace
 
-int pp_post_create(pp_ctx* ctx)
+static int post_create_one(pp_ctx* ctx, pp_slot& S)
 {
     pp_post* P = new pp_post();
-    ctx->post = P;
+    S.post = P;
     const pp_config& c = ctx->cfg;
     P->K = c.nms_pre_max;
     P->cb = pp_div_up(P->K, 64);
@@ -554,25 +554,41 @@ int pp_post_create(pp_ctx* ctx)
     return 0;
 }
 
+int pp_post_create(pp_ctx* ctx)
+{
+    for (pp_slot& S : ctx->slot) {
+        int rc = post_create_one(ctx, S);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 void pp_post_destroy(pp_ctx* ctx)
 {
-    pp_post* P = (pp_post*)ctx->post;
-    if (!P) return;
-    void* ptrs[] = {P->cand, P->counters, P->hist, P->shortl, P->sel, P->boxes, P->nbox, P->dirl, P->nmask};
-    for (void* q : ptrs)
-        if (q) (void)hipFree(q);
-    delete P;
-    ctx->post = nullptr;
+    for (pp_slot& S : ctx->slot) {
+        pp_post* P = (pp_post*)S.post;
+        if (!P) continue;
+        void* ptrs[] = {P->cand, P->counters, P->hist, P->shortl, P->sel, P->boxes, P->nbox, P->dirl, P->nmask};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+        delete P;
+        S.post = nullptr;
+    }
 }
 
 extern "C" int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
                               float* det, int32_t* det_count, int nms_mode, void* stream_)
 {
     if (!ctx) return PP_E_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
+    return pp_postprocess_slot(ctx, 0, cls, box, dir, mask, det, det_count, nms_mode, (hipStream_t)stream_);
+}
+
+int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box, const float* dir, const uint8_t* mask, float* det,
+                        int32_t* det_count, int nms_mode, hipStream_t stream)
+{
     if (!cls || !box || !dir || !mask || !det || !det_count) return pp_fail(ctx, PP_E_ARG, "pp_postprocess: null pointer");
     if (ctx->A == 0) return pp_fail(ctx, PP_E_STATE, "pp_postprocess: call pp_set_anchors first");
-    pp_post* P = (pp_post*)ctx->post;
+    pp_post* P = (pp_post*)ctx->slot[si].post;
     const pp_config& c = ctx->cfg;
     const int n = c.num_classes;
     for (int i = 0; i < n; ++i)

@@ -36,13 +36,22 @@ static int create_impl(pp_ctx* ctx)
     PP_HIP(hipSetDevice(ctx->device));
     size_t cells = (size_t)c.grid_size[0] * c.grid_size[1] * c.grid_size[2];
     size_t mp = (size_t)c.max_points;
-    PP_HIP(dalloc(&ctx->cell_first, cells));
-    PP_HIP(dalloc(&ctx->pt_cell, mp));
-    PP_HIP(dalloc(&ctx->pt_rank, mp));
-    PP_HIP(dalloc(&ctx->wave_cnt, mp / 64 + 8));
-    PP_HIP(dalloc(&ctx->slots, (size_t)c.max_voxels * c.max_num_points));
-    PP_HIP(dalloc(&ctx->vox_scalars, 4));
-    PP_HIP(dalloc(&ctx->occ, (size_t)ctx->gx * ctx->gy));
+    ctx->slot.resize(ctx->max_batch);
+    for (int b = 0; b < ctx->max_batch; ++b) {
+        pp_slot& S = ctx->slot[b];
+        PP_HIP(dalloc(&S.cell_first, cells));
+        PP_HIP(dalloc(&S.pt_cell, mp));
+        PP_HIP(dalloc(&S.pt_rank, mp));
+        PP_HIP(dalloc(&S.wave_cnt, mp / 64 + 8));
+        PP_HIP(dalloc(&S.slots, (size_t)c.max_voxels * c.max_num_points));
+        PP_HIP(dalloc(&S.vox_scalars, 4));
+        PP_HIP(dalloc(&S.occ, (size_t)ctx->gx * ctx->gy));
+        if (b > 0) PP_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        PP_HIP(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
+        PP_HIP(hipEventCreateWithFlags(&S.ev_post, hipEventDisableTiming));
+    }
+    PP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    PP_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
     PP_HIP(dalloc(&ctx->pfn_w, 9 * 64));
     PP_HIP(dalloc(&ctx->pfn_scale, 64));
     PP_HIP(dalloc(&ctx->pfn_shift, 64));
@@ -105,8 +114,17 @@ extern "C" void pp_destroy(pp_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     pp_net_destroy(ctx);
     pp_post_destroy(ctx);
-    void* ptrs[] = {ctx->cell_first, ctx->pt_cell, ctx->pt_rank, ctx->wave_cnt, ctx->slots, ctx->vox_scalars, ctx->occ,
-                    ctx->anchors, ctx->rect_x, ctx->rect_y, ctx->rects, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift,
+    for (pp_slot& S : ctx->slot) {
+        void* sp[] = {S.cell_first, S.pt_cell, S.pt_rank, S.wave_cnt, S.slots, S.vox_scalars, S.occ};
+        for (void* q : sp)
+            if (q) (void)hipFree(q);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.ev_pre) (void)hipEventDestroy(S.ev_pre);
+        if (S.ev_post) (void)hipEventDestroy(S.ev_post);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+    void* ptrs[] = {ctx->anchors, ctx->rect_x, ctx->rect_y, ctx->rects, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift,
                     ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, ctx->f_feat, ctx->f_canvas, ctx->f_mask,
                     ctx->f_cls, ctx->f_box, ctx->f_dir};
     for (void* p : ptrs)

@@ -30,6 +30,19 @@ struct pp_layer {
     float* bn_shift = nullptr;
 };
 
+struct pp_slot {
+    int32_t* cell_first = nullptr;  // [gx*gy*gz] first point index per cell
+    int32_t* pt_cell = nullptr;     // [max_points]
+    int32_t* pt_rank = nullptr;     // [max_points] pillar rank of first points
+    int32_t* wave_cnt = nullptr;    // [max_points/64 + 8]
+    int32_t* slots = nullptr;       // [max_voxels*T] ordered point indices per pillar
+    int32_t* vox_scalars = nullptr; // [4]: istar, P_all
+    int32_t* occ = nullptr;         // [gx*gy] occupancy -> summed-area table
+    void* post = nullptr;           // pp_post workspace (postprocess.hip)
+    hipStream_t stream = nullptr;   // internal stream of this slot (frames > 0 of a batch)
+    hipEvent_t ev_pre = nullptr, ev_post = nullptr;
+};
+
 struct pp_ctx {
     pp_config cfg;
     int device = 0;
@@ -38,15 +51,10 @@ struct pp_ctx {
     int gx = 0, gy = 0, H = 0, W = 0; // BEV grid and level-1 feature map (H = gx/2 along x, W = gy/2 along y)
     int max_batch = 1;                // frames per batched launch (cfg.max_batch)
     int64_t A = 0;                    // anchors
-    // ---- voxeliser workspace ----
-    int32_t* cell_first = nullptr; // [gx*gy*gz] first point index per cell
-    int32_t* pt_cell = nullptr;    // [max_points]
-    int32_t* pt_rank = nullptr;    // [max_points] pillar rank of first points
-    int32_t* wave_cnt = nullptr;   // [max_points/64 + 1]
-    int32_t* slots = nullptr;      // [max_voxels*T] ordered point indices per pillar
-    int32_t* vox_scalars = nullptr; // [4]: istar, P_all
-    // ---- anchor mask workspace ----
-    int32_t* occ = nullptr;        // [gx*gy] occupancy -> summed-area table
+    // ---- per-frame scratch of the integer stages: one slot per frame of a batch, so the frames'
+    //      voxelise / mask / post-processing can run concurrently on internal streams ----
+    std::vector<pp_slot> slot;     // [max_batch]; the single-stage entry points use slot 0
+    hipEvent_t ev_fork = nullptr, ev_mid = nullptr;
     float* anchors = nullptr;      // [A,7]
     int32_t* rect_x = nullptr;     // separable cell rectangles: [types, H, 2] (minx,maxx) / [types, W, 2] (miny,maxy)
     int32_t* rect_y = nullptr;
@@ -63,7 +71,6 @@ struct pp_ctx {
     float* pfn_scale = nullptr; // [64]
     float* pfn_shift = nullptr; // [64]
     void* net = nullptr;        // opaque pp_net (conv.hip)
-    void* post = nullptr;       // opaque pp_post workspace (postprocess.hip)
     // ---- measurement (pp_profile_begin/end) ----
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; // start/stop pairs
@@ -79,6 +86,12 @@ int pp_net_create(pp_ctx* ctx);
 void pp_net_destroy(pp_ctx* ctx);
 int pp_net_commit(pp_ctx* ctx);
 int pp_post_create(pp_ctx* ctx);
+// slot-aware internals of the public single-frame entry points
+int pp_voxelize_slot(pp_ctx* ctx, int s, const float* pts, int n, int nfeat, float* voxels, int32_t* coors, int32_t* npts,
+                     int32_t* num_pillars, hipStream_t stream);
+int pp_anchor_mask_slot(pp_ctx* ctx, int s, const int32_t* coors, const int32_t* num_pillars, uint8_t* mask, hipStream_t stream);
+int pp_postprocess_slot(pp_ctx* ctx, int s, const float* cls, const float* box, const float* dir, const uint8_t* mask, float* det,
+                        int32_t* det_count, int nms_mode, hipStream_t stream);
 int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream);          // nb canvases -> pre-norm [nb,320,H,W] + stats
 int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, int nb, hipStream_t stream); // norm+ReLU fused in the prologue
 void pp_post_destroy(pp_ctx* ctx);

@@ -159,7 +159,13 @@ extern "C" int pp_voxelize(pp_ctx* ctx, const float* pts, int n, int nfeat, floa
                            int32_t* npts, int32_t* num_pillars, void* stream_)
 {
     if (!ctx) return PP_E_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
+    return pp_voxelize_slot(ctx, 0, pts, n, nfeat, voxels, coors, npts, num_pillars, (hipStream_t)stream_);
+}
+
+int pp_voxelize_slot(pp_ctx* ctx, int si, const float* pts, int n, int nfeat, float* voxels, int32_t* coors, int32_t* npts,
+                     int32_t* num_pillars, hipStream_t stream)
+{
+    pp_slot& S = ctx->slot[si];
     const pp_config& cfg = ctx->cfg;
     if (n < 0 || n > cfg.max_points) return pp_fail(ctx, PP_E_ARG, "pp_voxelize: n exceeds cfg.max_points");
     if (nfeat != cfg.num_point_features || nfeat < 3) return pp_fail(ctx, PP_E_ARG, "pp_voxelize: nfeat mismatch");
@@ -169,18 +175,18 @@ extern "C" int pp_voxelize(pp_ctx* ctx, const float* pts, int n, int nfeat, floa
         return 0;
     }
     size_t cells = (size_t)cfg.grid_size[0] * cfg.grid_size[1] * cfg.grid_size[2];
-    PP_HIP(hipMemsetAsync(ctx->cell_first, 0x7F, cells * sizeof(int32_t), stream));
-    PP_HIP(hipMemsetAsync(ctx->slots, 0x7F, (size_t)cfg.max_voxels * cfg.max_num_points * sizeof(int32_t), stream));
-    PP_HIP(hipMemsetAsync(ctx->vox_scalars, 0x7F, 4 * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(S.cell_first, 0x7F, cells * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(S.slots, 0x7F, (size_t)cfg.max_voxels * cfg.max_num_points * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(S.vox_scalars, 0x7F, 4 * sizeof(int32_t), stream));
     int nb = pp_div_up(n, 256);
-    hipLaunchKernelGGL(vox_cell_first, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, ctx->pt_cell, ctx->cell_first);
-    hipLaunchKernelGGL(vox_flag_count, dim3(nb), dim3(256), 0, stream, ctx->pt_cell, ctx->cell_first, n, ctx->wave_cnt);
-    hipLaunchKernelGGL(vox_rank, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, ctx->pt_cell, ctx->cell_first,
-                       ctx->wave_cnt, ctx->pt_rank, coors, ctx->vox_scalars, num_pillars);
-    hipLaunchKernelGGL(vox_insert, dim3(nb), dim3(256), 0, stream, n, cfg, ctx->pt_cell, ctx->cell_first, ctx->pt_rank,
-                       ctx->vox_scalars, ctx->slots);
+    hipLaunchKernelGGL(vox_cell_first, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, S.pt_cell, S.cell_first);
+    hipLaunchKernelGGL(vox_flag_count, dim3(nb), dim3(256), 0, stream, S.pt_cell, S.cell_first, n, S.wave_cnt);
+    hipLaunchKernelGGL(vox_rank, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, S.pt_cell, S.cell_first,
+                       S.wave_cnt, S.pt_rank, coors, S.vox_scalars, num_pillars);
+    hipLaunchKernelGGL(vox_insert, dim3(nb), dim3(256), 0, stream, n, cfg, S.pt_cell, S.cell_first, S.pt_rank,
+                       S.vox_scalars, S.slots);
     int nt = cfg.max_voxels * cfg.max_num_points;
-    hipLaunchKernelGGL(vox_gather, dim3(pp_div_up(nt, 256)), dim3(256), 0, stream, pts, nfeat, cfg, ctx->slots, num_pillars,
+    hipLaunchKernelGGL(vox_gather, dim3(pp_div_up(nt, 256)), dim3(256), 0, stream, pts, nfeat, cfg, S.slots, num_pillars,
                        voxels, npts);
     PP_HIP(hipGetLastError());
     return 0;

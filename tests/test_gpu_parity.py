@@ -191,7 +191,7 @@ def test_backbone_small(norm, fw, synth):
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("force", ["wres", "wino tw8", "wino tw4", "k3s1 tw16 w1x4 t4x4", "k3s1 tw4 w2x2 t2x2", "k3s1 tw8 w2x2 t4x5"])
+@pytest.mark.parametrize("force", ["g1x1", "wres", "wino tw8", "wino tw4", "k3s1 tw16 w1x4 t4x4", "k3s1 tw4 w2x2 t2x2", "k3s1 tw8 w2x2 t4x5"])
 def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
     """Every tiling family (Winograd F(2x2,3x3) and direct, exact and masked-edge shapes) must give the
     same network output, whatever the autotuner would pick."""
@@ -203,6 +203,13 @@ def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
     net.load_state_dict(synth.seeded_state_dict(0))
     y = net.rpn(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-4)
+    if force == "g1x1":  # the head has a persistent 1x1 variant too: oracle head on the same features
+        sd = synth.seeded_state_dict(0)
+        p = net.heads(torch.from_numpy(g["y"]).cuda())
+        cls, box, dr = O.head(g["y"], sd)
+        np.testing.assert_allclose(p["cls_preds"].cpu().numpy(), cls, rtol=0, atol=5e-5)
+        np.testing.assert_allclose(p["box_preds"].cpu().numpy(), box, rtol=0, atol=5e-5)
+        np.testing.assert_allclose(p["dir_preds"].cpu().numpy(), dr, rtol=0, atol=5e-5)
 
 
 def test_head_layout(fw, synth):
