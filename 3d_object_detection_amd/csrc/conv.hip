@@ -568,13 +568,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) { sc_[c + q] = a_[q]; sh_[c + q] = b_[q]; } \
             }                                                                                    \
         }                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                      \
-            if (loff[r] >= 0) {                                                                  \
-                const bool inb_ = all_in || ((vmask >> r) & 1u);                                 \
-                _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                 \
-                    float v_ = xv[r][c];                                                         \
-                    if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, sc_[c], sh_[c]), 0.f);             \
-                    ib_[c * C::CS + loff[r]] = inb_ ? v_ : 0.f;                                  \
+        if (all_in) { /* interior patch: no zero-padding select (workgroup-uniform branch) */     \
+            _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                  \
+                if (loff[r] >= 0) {                                                              \
+                    _Pragma("unroll") for (int c = 0; c < KC; ++c) {                             \
+                        float v_ = xv[r][c];                                                     \
+                        if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, sc_[c], sh_[c]), 0.f);         \
+                        ib_[c * C::CS + loff[r]] = v_;                                           \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < C::PR; ++r) {                                  \
+                if (loff[r] >= 0) {                                                              \
+                    const bool inb_ = (vmask >> r) & 1u;                                         \
+                    _Pragma("unroll") for (int c = 0; c < KC; ++c) {                             \
+                        float v_ = xv[r][c];                                                     \
+                        if (p.pre != PRE_RAW) v_ = fmaxf(fmaf(v_, sc_[c], sh_[c]), 0.f);         \
+                        ib_[c * C::CS + loff[r]] = inb_ ? v_ : 0.f;                              \
+                    }                                                                            \
                 }                                                                                \
             }                                                                                    \
         }                                                                                        \

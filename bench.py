@@ -4,10 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one frame per GPU through pp_infer_frame (batch=1, as the reference's loop train.py:219-242)
-plus the async D2H of its detection record.  Workload: configs/eight_20cm.json, synthetic KITTI-shape
+A step = one pass of `--batch` independent frames per GPU through pp_infer_batch (each frame keeps the
+reference's batch=1 semantics, train.py:219-242: no statistic is shared between frames; the frames only share
+kernel launches) plus the async D2H of their detection records.  Workload: configs/eight_20cm.json, synthetic KITTI-shape
 20k-point clouds already resident in HBM, random-init weights of the reference architecture.
-Frames are sharded by index across ranks (weak scaling: one frame per rank per step, no data-path
+Frames are sharded by index across ranks (weak scaling: `--batch` frames per rank per step, no data-path
 collective); RCCL only gathers the detection records once at the end of the timed region.
 Rank 0 prints ONE JSON line with `roofline` (dominant conv kernel timed with HIP events on its launch
 stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle on the host cores).
@@ -86,14 +87,14 @@ def cpu_baseline(synth, n_frames=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="eight_20cm")
     ap.add_argument("--cls-bias", type=float, default=None, help="'trained-like' head bias (e.g. -4.6); default random init")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: independent frames run on separate HIP streams (one pp_ctx each) so one "
                          "frame's kernel tails / small kernels overlap another frame's MFMA work")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=16,
                     help="independent frames per pass on one stream (pp_infer_batch: frame = grid.z of the conv launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
