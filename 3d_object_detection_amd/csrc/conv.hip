@@ -78,6 +78,10 @@ struct ConvP {
     size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
     size_t pre_fs, stat_fs;                        // doubles
     int nb;                                        // frames (persistent kernels loop over them; others use grid.z)
+    // sparse BEV input of the first conv: pillar-index map [Hin*Win] (-1 = empty) + PFN rows [P][64]
+    const int32_t* pmap;
+    const float* feat;
+    size_t pmap_fs, feat_fs;
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -217,7 +221,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const size_t in_plane = (size_t)p.Hin * p.Win;
-    const int nchunk = (p.dbg & 16) ? 0 : p.Cin / KC;
+    int nchunk = (p.dbg & 16) ? 0 : p.Cin / KC;
+    // Sparse BEV input (first conv): each staged position carries the pillar id of its cell; channels come from
+    // the [P][64] PFN rows.  A workgroup whose whole halo patch is empty has an all-zero output: skip its MFMA loop.
+    const bool sparse = p.pmap != nullptr;
+    int pid[C::PR];
+    const float* gfeat = nullptr;
+    if (sparse) {
+        const int32_t* gmap = p.pmap + fz * p.pmap_fs;
+        gfeat = p.feat + fz * p.feat_fs;
+        int any = 0;
+#pragma unroll
+        for (int r = 0; r < C::PR; ++r) {
+            pid[r] = ((vmask >> r) & 1u) ? gmap[goff[r]] : -1;
+            any |= (pid[r] >= 0);
+            if (pid[r] < 0) vmask &= ~(1u << r);
+            goff[r] = pid[r] >= 0 ? pid[r] * 64 : 0; // reuse goff as the row offset into feat
+        }
+        if (!__syncthreads_or(any)) nchunk = 0;
+    }
     const float4* wsrc = reinterpret_cast<const float4*>(p.w) + (size_t)blockIdx.y * (p.Cin / KC) * C::W4;
 
     float xv[C::PR][KC];
@@ -226,9 +248,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
 #define PP_LOAD_CHUNK(CH)                                                                        \
     {                                                                                            \
-        const float* base_ = gin + (size_t)((CH) * KC) * in_plane;                              \
-        _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                        \
-            _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
+        if (sparse) {                                                                            \
+            const float* fb_ = gfeat + (CH) * KC;                                                \
+            _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                    \
+                _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = fb_[goff[r] + c];      \
+        } else {                                                                                 \
+            const float* base_ = gin + (size_t)((CH) * KC) * in_plane;                           \
+            _Pragma("unroll") for (int r = 0; r < C::PR; ++r)                                    \
+                _Pragma("unroll") for (int c = 0; c < KC; ++c) xv[r][c] = base_[(size_t)c * in_plane + goff[r]]; \
+        }                                                                                        \
         const f32x4* g_ = wsrc4 + (size_t)(CH) * C::W4;                                          \
         _Pragma("unroll") for (int r = 0; r < C::WR; ++r) {                                      \
             const int e_ = tid + r * C::THREADS;                                                 \
@@ -1631,7 +1659,8 @@ constexpr size_t STAT_FS = (size_t)24 * NREP * 320 * 2; // doubles of statistics
 
 int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, float* out, const float* res,
                 const NormRef& pre, double* stat_acc, int stat_C, int Hout, int Wout, hipStream_t stream,
-                float* out_box = nullptr, float* out_dir = nullptr, int B = 1, size_t out_fs = 0, size_t in_fs = 0)
+                float* out_box = nullptr, float* out_dir = nullptr, int B = 1, size_t out_fs = 0, size_t in_fs = 0,
+                const int32_t* pmap = nullptr, const float* feat = nullptr)
 {
     pp_net* net = (pp_net*)ctx->net;
     ConvP p;
@@ -1654,6 +1683,9 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         p.dir_fs = (size_t)18 * hw;
         p.pre_fs = pre.fs;
         p.stat_fs = STAT_FS;
+        p.pmap = pmap; p.feat = feat;
+        p.pmap_fs = (size_t)Hin * Win;
+        p.feat_fs = (size_t)ctx->cfg.max_voxels * 64;
     }
     const Variant& v = L.var;
     dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm), B);
@@ -2020,7 +2052,7 @@ int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const
 
 // canvas [64,gx,gy] -> up [320,H,W] PRE-norm (+ statistics); the head (or pp_backbone's final pass)
 // applies the last norm + ReLU.
-int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream)
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream, const int32_t* pmap, const float* feat)
 {
     pp_net* net = (pp_net*)ctx->net;
     const int H = ctx->H, W = ctx->W;
@@ -2041,7 +2073,7 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream
         int rc;
         // strided conv (raw input) -> Bf[0] + stats(site 0)
         if ((rc = launch_conv(ctx, net->layers[li++], x, Hin, Win, Bf[0], nullptr, raw, stat_slot(ctx, site_block(b, 0)), c, h, w, stream,
-                              nullptr, nullptr, nb))) return rc;
+                              nullptr, nullptr, nb, 0, 0, b == 0 ? pmap : nullptr, b == 0 ? feat : nullptr))) return rc;
         // y = relu(norm(Bf[0])) -> Bf[1] + stats(site 1) (the first Resnet2 unit's leading norm)
         if ((rc = launch_norm_relu(ctx, Bf[0], Bf[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
                                    stat_slot(ctx, site_block(b, 1)), stream, nb))) return rc;
@@ -2102,7 +2134,7 @@ extern "C" int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, voi
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_backbone: weights not committed");
     if (!canvas || !rpn_out) return pp_fail(ctx, PP_E_ARG, "pp_backbone: null pointer");
-    int rc = pp_run_backbone(ctx, canvas, 1, stream);
+    int rc = pp_run_backbone(ctx, canvas, 1, stream, nullptr, nullptr);
     if (rc) return rc;
     pp_net* net = (pp_net*)ctx->net;
     const int HW = ctx->H * ctx->W;

@@ -17,7 +17,7 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
     const pp_config& c = ctx->cfg;
     const size_t mv = (size_t)c.max_voxels;
     const size_t vs = mv * c.max_num_points * c.num_point_features;
-    const size_t plane = (size_t)ctx->gx * ctx->gy * 64;
+    const size_t cells = (size_t)ctx->gx * ctx->gy;
     const size_t A = (size_t)ctx->A;
     int rc;
     // Fork: the integer stages of the nb frames are independent and latency-bound, so frames 1.. run on the
@@ -34,13 +34,14 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
         if ((rc = pp_voxelize_slot(ctx, b, pts_h[b], n_h[b], c.num_point_features, vox, coors, npts, num, st))) return rc;
         if ((rc = pp_anchor_mask_slot(ctx, b, coors, num, ctx->f_mask + b * A, st))) return rc;
         if ((rc = pp_pfn(ctx, vox, coors, npts, num, feat, st))) return rc;
-        if ((rc = pp_scatter(ctx, feat, coors, num, ctx->f_canvas + b * plane, st))) return rc;
+        if ((rc = pp_pillar_map(ctx, coors, num, ctx->f_pmap + b * cells, st))) return rc;
         if (b > 0) {
             PP_HIP(hipEventRecord(ctx->slot[b].ev_pre, st));
             PP_HIP(hipStreamWaitEvent(stream, ctx->slot[b].ev_pre, 0));
         }
     }
-    if ((rc = pp_run_backbone(ctx, ctx->f_canvas, nb, stream))) return rc;
+    // sparse BEV: the first conv gathers from (pillar map, PFN rows); no dense canvas, no 164 MB memset per frame
+    if ((rc = pp_run_backbone(ctx, nullptr, nb, stream, ctx->f_pmap, ctx->f_feat))) return rc;
     if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
     const size_t rows = (size_t)c.num_classes * c.nms_post_max;
     if (nb > 1) PP_HIP(hipEventRecord(ctx->ev_mid, stream));

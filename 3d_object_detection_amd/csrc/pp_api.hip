@@ -62,7 +62,8 @@ static int create_impl(pp_ctx* ctx)
     PP_HIP(dalloc(&ctx->f_npts, mv));
     PP_HIP(dalloc(&ctx->f_num, 4 * (size_t)ctx->max_batch));
     PP_HIP(dalloc(&ctx->f_feat, mv * 64));
-    PP_HIP(dalloc(&ctx->f_canvas, (size_t)ctx->max_batch * 64 * ctx->gx * ctx->gy));
+    PP_HIP(dalloc(&ctx->f_canvas, (size_t)64 * ctx->gx * ctx->gy)); // dense canvas: stand-alone pp_scatter/pp_backbone only
+    PP_HIP(dalloc(&ctx->f_pmap, (size_t)ctx->max_batch * ctx->gx * ctx->gy));
     size_t HW = (size_t)ctx->H * ctx->W;
     size_t Amax = HW * c.num_anchor_per_loc * ctx->max_batch;
     PP_HIP(dalloc(&ctx->f_mask, Amax));
@@ -125,7 +126,7 @@ extern "C" void pp_destroy(pp_ctx* ctx)
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     void* ptrs[] = {ctx->anchors, ctx->rect_x, ctx->rect_y, ctx->rects, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift,
-                    ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, ctx->f_feat, ctx->f_canvas, ctx->f_mask,
+                    ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, ctx->f_feat, ctx->f_canvas, ctx->f_mask, ctx->f_pmap,
                     ctx->f_cls, ctx->f_box, ctx->f_dir};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

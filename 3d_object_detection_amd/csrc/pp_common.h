@@ -62,7 +62,7 @@ struct pp_ctx {
     int rect_separable = 0;
     // ---- frame buffers (pp_infer_frame) ----
     float* f_voxels = nullptr; int32_t* f_coors = nullptr; int32_t* f_npts = nullptr; int32_t* f_num = nullptr;
-    float* f_feat = nullptr; float* f_canvas = nullptr; uint8_t* f_mask = nullptr;
+    float* f_feat = nullptr; float* f_canvas = nullptr; uint8_t* f_mask = nullptr; int32_t* f_pmap = nullptr;
     float* f_cls = nullptr; float* f_box = nullptr; float* f_dir = nullptr;
     // ---- network ----
     std::map<std::string, pp_tensor_h> host_w;
@@ -92,7 +92,9 @@ int pp_voxelize_slot(pp_ctx* ctx, int s, const float* pts, int n, int nfeat, flo
 int pp_anchor_mask_slot(pp_ctx* ctx, int s, const int32_t* coors, const int32_t* num_pillars, uint8_t* mask, hipStream_t stream);
 int pp_postprocess_slot(pp_ctx* ctx, int s, const float* cls, const float* box, const float* dir, const uint8_t* mask, float* det,
                         int32_t* det_count, int nms_mode, hipStream_t stream);
-int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream);          // nb canvases -> pre-norm [nb,320,H,W] + stats
+// nb canvases (or, when pmap != nullptr, nb sparse BEV inputs: pillar-index maps + PFN rows) -> pre-norm [nb,320,H,W] + stats
+int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream, const int32_t* pmap, const float* feat);
+int pp_pillar_map(pp_ctx* ctx, const int32_t* coors, const int32_t* num_pillars, int32_t* pmap, hipStream_t stream);
 int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, int nb, hipStream_t stream); // norm+ReLU fused in the prologue
 void pp_post_destroy(pp_ctx* ctx);
 
