@@ -3,6 +3,7 @@
 // A batch carries nb independent frames through ONE set of conv/deconv/head launches (grid.z = frame):
 // the launches get several rounds of workgroups, so the prologue/epilogue of one round overlaps the MFMA
 // phase of the next instead of being exposed once per frame and layer.
+#include <cstdlib>
 #include "pp_common.h"
 
 extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int32_t* n_h, int nb, float* det, int32_t* det_count,
@@ -20,12 +21,20 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
     const size_t cells = (size_t)ctx->gx * ctx->gy;
     const size_t A = (size_t)ctx->A;
     int rc;
+    // frames are dealt round-robin to (1 + naux) streams: the caller's and naux internal ones.  The GPU exposes
+    // 4 hardware queues by default, so more than 3 internal streams only adds queue-switch overhead.
+    static const int naux_env = getenv("PP_AUX_STREAMS") ? atoi(getenv("PP_AUX_STREAMS")) : 3;
+    const int naux = naux_env < 0 ? 0 : (naux_env > nb - 1 ? nb - 1 : naux_env);
+    auto lane_of = [&](int b) { return naux == 0 ? 0 : b % (naux + 1); }; // 0 = caller's stream, k = slot k's stream
     // Fork: the integer stages of the nb frames are independent and latency-bound, so frames 1.. run on the
     // slots' internal streams concurrently with frame 0 (caller's stream); all join before the shared conv launches.
-    if (nb > 1) PP_HIP(hipEventRecord(ctx->ev_fork, stream));
+    if (naux > 0) {
+        PP_HIP(hipEventRecord(ctx->ev_fork, stream));
+        for (int k = 1; k <= naux; ++k) PP_HIP(hipStreamWaitEvent(ctx->slot[k].stream, ctx->ev_fork, 0));
+    }
     for (int b = 0; b < nb; ++b) {
-        hipStream_t st = (b == 0) ? stream : ctx->slot[b].stream;
-        if (b > 0) PP_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        const int ln = lane_of(b);
+        hipStream_t st = (ln == 0) ? stream : ctx->slot[ln].stream;
         float* vox = ctx->f_voxels + b * vs;
         int32_t* coors = ctx->f_coors + b * mv * 3;
         int32_t* npts = ctx->f_npts + b * mv;
@@ -35,25 +44,28 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
         if ((rc = pp_anchor_mask_slot(ctx, b, coors, num, ctx->f_mask + b * A, st))) return rc;
         if ((rc = pp_pfn(ctx, vox, coors, npts, num, feat, st))) return rc;
         if ((rc = pp_pillar_map(ctx, coors, num, ctx->f_pmap + b * cells, st))) return rc;
-        if (b > 0) {
-            PP_HIP(hipEventRecord(ctx->slot[b].ev_pre, st));
-            PP_HIP(hipStreamWaitEvent(stream, ctx->slot[b].ev_pre, 0));
-        }
+    }
+    for (int k = 1; k <= naux; ++k) { // join
+        PP_HIP(hipEventRecord(ctx->slot[k].ev_pre, ctx->slot[k].stream));
+        PP_HIP(hipStreamWaitEvent(stream, ctx->slot[k].ev_pre, 0));
     }
     // sparse BEV: the first conv gathers from (pillar map, PFN rows); no dense canvas, no 164 MB memset per frame
     if ((rc = pp_run_backbone(ctx, nullptr, nb, stream, ctx->f_pmap, ctx->f_feat))) return rc;
     if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
     const size_t rows = (size_t)c.num_classes * c.nms_post_max;
-    if (nb > 1) PP_HIP(hipEventRecord(ctx->ev_mid, stream));
+    if (naux > 0) {
+        PP_HIP(hipEventRecord(ctx->ev_mid, stream));
+        for (int k = 1; k <= naux; ++k) PP_HIP(hipStreamWaitEvent(ctx->slot[k].stream, ctx->ev_mid, 0));
+    }
     for (int b = 0; b < nb; ++b) {
-        hipStream_t st = (b == 0) ? stream : ctx->slot[b].stream;
-        if (b > 0) PP_HIP(hipStreamWaitEvent(st, ctx->ev_mid, 0));
+        const int ln = lane_of(b);
+        hipStream_t st = (ln == 0) ? stream : ctx->slot[ln].stream;
         if ((rc = pp_postprocess_slot(ctx, b, ctx->f_cls + b * A, ctx->f_box + b * A * 7, ctx->f_dir + b * A * 2, ctx->f_mask + b * A,
                                       det + b * rows * 9, det_count + b * PP_DET_COUNT_STRIDE, nms_mode, st))) return rc;
-        if (b > 0) {
-            PP_HIP(hipEventRecord(ctx->slot[b].ev_post, st));
-            PP_HIP(hipStreamWaitEvent(stream, ctx->slot[b].ev_post, 0));
-        }
+    }
+    for (int k = 1; k <= naux; ++k) {
+        PP_HIP(hipEventRecord(ctx->slot[k].ev_post, ctx->slot[k].stream));
+        PP_HIP(hipStreamWaitEvent(stream, ctx->slot[k].ev_post, 0));
     }
     return 0;
 }

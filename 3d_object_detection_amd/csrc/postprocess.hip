@@ -376,7 +376,7 @@ __device__ float rotated_iou_dev(const float* r1, const float* r2)
 // ---------------------------------------------------------------- Q5
 // grid (col tile, row tile, class); 64 threads; lane = COLUMN box, loop over the 64 row boxes;
 // the 64-bit ballot of the wave is the mask word of that row.
-// TRANSPOSED suppression mask: maskT[col][rt] holds, for column box `col`, the bits r of the row boxes
+// TRANSPOSED suppression mask, row-tile major: maskT[rt][col] holds, for column box `col`, the bits r of the row boxes
 // (rt*64 + r) that suppress it (IoU > thr and row < col).  One wave per (col tile, row tile); the lane owning a
 // column accumulates its own word while the row boxes are broadcast with readlane -- no ballot, no loads in the loop.
 __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, int nstride, const int32_t* __restrict__ nsel_p,
@@ -408,21 +408,23 @@ __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, i
             if (iou > thr) word |= 1ull << r;
         }
     }
-    if (col < n) maskT[((size_t)c * K + col) * cb + rt] = word;
+    if (col < n) maskT[((size_t)c * cb + rt) * K + col] = word;
 }
 
 // Greedy sweep (nms_postprocess, nms.py:85-102) for one class by ONE wavefront on the transposed mask.
 // Lane j keeps the suppression word of tile j.  Per tile t: every lane loads its column's words for tile t
 // (diagonal) and the later tiles need only one load + one ballot each.  Returns #kept (<= max_keep).
-__device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int cb, int max_keep, int* __restrict__ keep)
+__device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int K, int cb, int max_keep, int* __restrict__ keep)
 {
+    // maskT[t * K + col]: all loads of a step are 512 contiguous bytes
     const int lane = threadIdx.x & 63;
     uint64_t remv = 0ull; // lane j: columns of tile j already suppressed
     int nk = 0;
     const int tiles = (n + 63) >> 6;
     for (int t = 0; t < tiles && nk < max_keep; ++t) {
         const int i = t * 64 + lane;
-        const uint64_t diag = (i < n) ? maskT[(size_t)i * cb + t] : 0ull; // rows of tile t suppressing column i
+        const uint64_t* row = maskT + (size_t)t * K;
+        const uint64_t diag = (i < n) ? row[i] : 0ull; // rows of tile t suppressing column i
         const uint64_t rt = __shfl(remv, t);
         const int valid = min(64, n - t * 64);
         uint64_t alive = ~rt & (valid == 64 ? ~0ull : ((1ull << valid) - 1ull));
@@ -441,9 +443,8 @@ __device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int cb
             uint64_t w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const int cidx = j * 64 + lane;
-                w[u] = (j < tiles && cidx < n) ? maskT[(size_t)cidx * cb + t] : 0ull;
+                const int cidx = (j0 + u) * 64 + lane;
+                w[u] = (j0 + u < tiles && cidx < n) ? row[cidx] : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(512) nms_reduce(pp_config cfg, const uint64_t*
         const int c = wave;
         const int n = counters[c * 8 + 3];
         int* keep = keep_ws + (size_t)c * K;
-        const int nk = nms_greedy_wave(mask + (size_t)c * K * cb, n, cb, cfg.nms_post_max, keep);
+        const int nk = nms_greedy_wave(mask + (size_t)c * K * cb, n, K, cb, cfg.nms_post_max, keep);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // direction flip + range mask (quirk: dims vs upper limits, inference.py:107-109), stable compaction
@@ -539,8 +540,9 @@ static int post_create_one(pp_ctx* ctx, pp_slot& S)
     P->cand_cap = cap > 0 ? cap : 1;
     const int n = c.num_classes;
     PP_HIP(hipMalloc((void**)&P->cand, (size_t)n * P->cand_cap * sizeof(uint64_t)));
-    PP_HIP(hipMalloc((void**)&P->counters, (size_t)n * 8 * sizeof(int32_t)));
-    PP_HIP(hipMalloc((void**)&P->hist, (size_t)n * NBINS * sizeof(int32_t)));
+    // hist | counters share one allocation: one zero fill per frame
+    PP_HIP(hipMalloc((void**)&P->hist, (size_t)n * (NBINS + 8) * sizeof(int32_t)));
+    P->counters = P->hist + (size_t)n * NBINS;
     PP_HIP(hipMalloc((void**)&P->shortl, (size_t)n * SHORT_CAP * sizeof(uint64_t)));
     PP_HIP(hipMalloc((void**)&P->sel, (size_t)n * P->K * sizeof(uint64_t)));
     PP_HIP(hipMalloc((void**)&P->boxes, (size_t)n * P->K * 7 * sizeof(float)));
@@ -568,7 +570,7 @@ void pp_post_destroy(pp_ctx* ctx)
     for (pp_slot& S : ctx->slot) {
         pp_post* P = (pp_post*)S.post;
         if (!P) continue;
-        void* ptrs[] = {P->cand, P->counters, P->hist, P->shortl, P->sel, P->boxes, P->nbox, P->dirl, P->nmask};
+        void* ptrs[] = {P->cand, P->hist, P->shortl, P->sel, P->boxes, P->nbox, P->dirl, P->nmask};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         delete P;
@@ -593,8 +595,7 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
     const int n = c.num_classes;
     for (int i = 0; i < n; ++i)
         if (c.class_end[i] > ctx->A) return pp_fail(ctx, PP_E_ARG, "class range exceeds anchor count");
-    PP_HIP(hipMemsetAsync(P->counters, 0, (size_t)n * 8 * sizeof(int32_t), stream));
-    PP_HIP(hipMemsetAsync(P->hist, 0, (size_t)n * NBINS * sizeof(int32_t), stream));
+    PP_HIP(hipMemsetAsync(P->hist, 0, (size_t)n * (NBINS + 8) * sizeof(int32_t), stream)); // hist + counters
     hipLaunchKernelGGL(post_filter, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n), dim3(256), 0, stream, cls, mask, c, c.score_threshold,
                        P->thr_bits, P->bin_shift, P->cand_cap, P->cand, P->counters, P->hist);
     hipLaunchKernelGGL(post_thresh, dim3(n), dim3(1024), 0, stream, P->hist, P->counters, P->K);
@@ -689,7 +690,7 @@ __global__ void __launch_bounds__(1024) k_nms_sort(const float* __restrict__ det
 __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ order, int n, int cb,
                                                    int32_t* __restrict__ tmp, int32_t* __restrict__ keep, int32_t* __restrict__ nkeep)
 {
-    const int nk = nms_greedy_wave(mask, n, cb, n, tmp);
+    const int nk = nms_greedy_wave(mask, n, n, cb, n, tmp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (int k = threadIdx.x; k < nk; k += 64) keep[k] = order[tmp[k]];

@@ -39,12 +39,14 @@ static int create_impl(pp_ctx* ctx)
     ctx->slot.resize(ctx->max_batch);
     for (int b = 0; b < ctx->max_batch; ++b) {
         pp_slot& S = ctx->slot[b];
-        PP_HIP(dalloc(&S.cell_first, cells));
+        // cell_first | slots | vox_scalars share one allocation: one 0x7F fill per frame covers all three
+        const size_t nslots = (size_t)c.max_voxels * c.max_num_points;
+        PP_HIP(dalloc(&S.cell_first, cells + nslots + 4));
+        S.slots = S.cell_first + cells;
+        S.vox_scalars = S.slots + nslots;
         PP_HIP(dalloc(&S.pt_cell, mp));
         PP_HIP(dalloc(&S.pt_rank, mp));
         PP_HIP(dalloc(&S.wave_cnt, mp / 64 + 8));
-        PP_HIP(dalloc(&S.slots, (size_t)c.max_voxels * c.max_num_points));
-        PP_HIP(dalloc(&S.vox_scalars, 4));
         PP_HIP(dalloc(&S.occ, (size_t)ctx->gx * ctx->gy));
         if (b > 0) PP_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         PP_HIP(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
@@ -116,7 +118,7 @@ extern "C" void pp_destroy(pp_ctx* ctx)
     pp_net_destroy(ctx);
     pp_post_destroy(ctx);
     for (pp_slot& S : ctx->slot) {
-        void* sp[] = {S.cell_first, S.pt_cell, S.pt_rank, S.wave_cnt, S.slots, S.vox_scalars, S.occ};
+        void* sp[] = {S.cell_first, S.pt_cell, S.pt_rank, S.wave_cnt, S.occ};
         for (void* q : sp)
             if (q) (void)hipFree(q);
         if (S.stream) (void)hipStreamDestroy(S.stream);

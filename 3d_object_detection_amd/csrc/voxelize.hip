@@ -175,9 +175,8 @@ int pp_voxelize_slot(pp_ctx* ctx, int si, const float* pts, int n, int nfeat, fl
         return 0;
     }
     size_t cells = (size_t)cfg.grid_size[0] * cfg.grid_size[1] * cfg.grid_size[2];
-    PP_HIP(hipMemsetAsync(S.cell_first, 0x7F, cells * sizeof(int32_t), stream));
-    PP_HIP(hipMemsetAsync(S.slots, 0x7F, (size_t)cfg.max_voxels * cfg.max_num_points * sizeof(int32_t), stream));
-    PP_HIP(hipMemsetAsync(S.vox_scalars, 0x7F, 4 * sizeof(int32_t), stream));
+    // cell_first | slots | vox_scalars are one allocation (pp_api.hip): a single fill
+    PP_HIP(hipMemsetAsync(S.cell_first, 0x7F, (cells + (size_t)cfg.max_voxels * cfg.max_num_points + 4) * sizeof(int32_t), stream));
     int nb = pp_div_up(n, 256);
     hipLaunchKernelGGL(vox_cell_first, dim3(nb), dim3(256), 0, stream, pts, n, nfeat, cfg, S.pt_cell, S.cell_first);
     hipLaunchKernelGGL(vox_flag_count, dim3(nb), dim3(256), 0, stream, S.pt_cell, S.cell_first, n, S.wave_cnt);
