@@ -893,7 +893,7 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
     float* rawl = ul + C::U_FLOATS;                     // [NW][NT][KC][CS]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     float* scl = rawl + C::NW * NT * C::RAW_FLOATS + wave * 2 * CIN; // wave-private: waves may be on different frames
     float* shl = scl + CIN;
@@ -1177,12 +1177,12 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 {
     constexpr int BM = MT * 16;
     constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
-    constexpr int PD = 6; // B-operand ring depth (steps in flight)
+    constexpr int PD = 8; // B-operand ring depth (steps in flight); even, and K % (4 * PD) == 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                         // [K][BMP]
     const int K = p.Cin;
     float* sc_all = wl + (size_t)K * BMP;     // [8 waves][2][K]  wave-private (scale, shift)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: frame, item and the buffer descriptor stay in SGPRs
     const int m = lane & 15, kq = lane >> 4;
     float* scl = sc_all + (size_t)wave * 2 * K;
     float* shl = scl + K;
@@ -1244,8 +1244,8 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 
     const int aoff = kq * BMP + m;
     for (int item = gw; item < total; item += gstride) {
-        const int fr = item / items_per_frame;
-        const int pix0 = (item - fr * items_per_frame) * (NT * 16);
+        const int fr = __builtin_amdgcn_readfirstlane(item / items_per_frame); // the division runs on the VALU: pin the
+        const int pix0 = __builtin_amdgcn_readfirstlane((item - fr * items_per_frame) * (NT * 16)); // wave-uniform results in SGPRs
         if (fr != stat_frame) { flush_stats(stat_frame); stat_frame = fr; }
         if (p.pre != PRE_RAW && fr != pre_frame) {
             for (int c = lane; c < K; c += 64) {
@@ -1279,37 +1279,60 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // K % (4 * PD) == 0 (layer_menu offers this kernel only then): no tail steps.
+        // Per step: the B quad of step st+PD-1 is requested (buffer load: lane offset in a VGPR, the channel-quad
+        // offset in an SGPR -- no address VALU), the A fragments and the normalised B values of step st+1 are
+        // prepared in the shadow of this step's MT*NT MFMAs, then the MFMAs issue.  The last ring is peeled so
+        // that no step carries a run-time condition.
         f32x4 bq[PD];
         const int nsteps = K / 4;
-#define G1_LOADB(S, SLOT) bq[SLOT] = *reinterpret_cast<const f32x4*>(gin + (size_t)(S) * 4 * plane + pof);
+        // descriptor base pinned to SGPRs (a VGPR-resident descriptor costs a waterfall loop per load)
+        const uint64_t bp_ = (uint64_t)(p.in + (size_t)fr * p.in_fs);
+        const uint64_t bps_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp_);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bps_), 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned bvoff = ((unsigned)kq * (unsigned)plane + (unsigned)pof) * 4u;
+        const unsigned bstep = 16u * (unsigned)plane; // bytes between channel quads
+#define G1_LOADB(S, SLOT) bq[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff, (unsigned)(S) * bstep, 0));
+#define G1_PREP(S, SLOT, PAR)                                                                    \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[PAR][i] = wl[(S) * 4 * BMP + aoff + i * 16]; \
+        if (p.pre != PRE_RAW) {                                                                  \
+            const float sc = scl[(S) * 4 + kq], sh = shl[(S) * 4 + kq];                          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = fmaxf(fmaf(bq[SLOT][j], sc, sh), 0.f); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = bq[SLOT][j];              \
+        }                                                                                        \
+    }
+#define G1_MFMAS(PAR)                                                                            \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PAR][i], b[PAR][j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+        float a[2][MT], b[2][NT];
 #pragma unroll
-        for (int s0 = 0; s0 < PD - 1; ++s0)
-            if (s0 < nsteps) G1_LOADB(s0, s0)
-        for (int sb = 0; sb < nsteps; sb += PD) {
+        for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
+        G1_PREP(0, 0, 0)
+        int sb = 0;
+        for (; sb < nsteps - PD; sb += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int st = sb + u;
-                if (st < nsteps) {
-                    if (st + PD - 1 < nsteps) G1_LOADB(st + PD - 1, (u + PD - 1) % PD)
-                    float a[MT], b[NT];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) a[i] = wl[(size_t)st * 4 * BMP + aoff + i * 16];
-                    if (p.pre != PRE_RAW) {
-                        const float sc = scl[st * 4 + kq], sh = shl[st * 4 + kq];
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) b[j] = fmaxf(fmaf(bq[u][j], sc, sh), 0.f);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) b[j] = bq[u][j];
-                    }
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                }
+                G1_LOADB(sb + u + PD - 1, (u + PD - 1) % PD)
+                G1_PREP(sb + u + 1, (u + 1) % PD, (u + 1) & 1)
+                G1_MFMAS(u & 1)
             }
         }
+        // last ring: only its first step still has a quad to request, the last one nothing to prepare
+        G1_LOADB(sb + PD - 1, PD - 1)
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            if (u + 1 < PD) G1_PREP(sb + u + 1, (u + 1) % PD, (u + 1) & 1)
+            G1_MFMAS(u & 1)
+        }
+#undef G1_MFMAS
+#undef G1_PREP
 #undef G1_LOADB
 
         // ---- epilogue of this item (lane m owns pixels pxb .. pxb+3, one per N-tile) ----
@@ -1317,9 +1340,13 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         float* gbox = p.out_box ? p.out_box + (size_t)fr * p.box_fs : nullptr;
         float* gdir = p.out_dir ? p.out_dir + (size_t)fr * p.dir_fs : nullptr;
         if (pok) {
+            // the row-dependent addresses and biases are lane constants: without this the compiler hoists all of
+            // them out of the item loop and spills them around the MFMA loop; recomputing per item is ~free
+            int kq_e = kq;
+            asm volatile("" : "+v"(kq_e));
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int row0 = co0 + i * 16 + kq * 4;
+                const int row0 = co0 + i * 16 + kq_e * 4;
                 if (row0 >= p.Cout) continue;
                 if (EPI == EPI_PLAIN) {
 #pragma unroll
@@ -1580,9 +1607,9 @@ void conv_menu(std::vector<Variant>& m)
 
 void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0)
 {
+    const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
     if (kind == 2) {
-        menu.push_back(make_g1<6, 4, EPI_HEAD>());
-        menu.push_back(make_g1<3, 4, EPI_HEAD>());
+        if (g1ok) { menu.push_back(make_g1<6, 4, EPI_HEAD>()); menu.push_back(make_g1<3, 4, EPI_HEAD>()); }
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 5, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 2, 2, 3, 5, 1, 16, EPI_HEAD>());
@@ -1590,9 +1617,9 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         menu.push_back(make_variant<1, 1, 8, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 8, 2, 2, 3, 4, 2, 16, EPI_HEAD>());
     } else if (kind == 1) {
-        if (up == 1) { conv_menu<1, 1, 16, EPI_PLAIN>(menu); menu.push_back(make_g1<4, 4, EPI_PLAIN>()); menu.push_back(make_g1<2, 4, EPI_PLAIN>()); }
-        else if (up == 2) { conv_menu<1, 1, 16, EPI_UP2>(menu); menu.push_back(make_g1<4, 4, EPI_UP2>()); menu.push_back(make_g1<8, 4, EPI_UP2>()); }
-        else { conv_menu<1, 1, 16, EPI_UP4>(menu); menu.push_back(make_g1<4, 4, EPI_UP4>()); menu.push_back(make_g1<8, 4, EPI_UP4>()); }
+        if (up == 1) { conv_menu<1, 1, 16, EPI_PLAIN>(menu); if (g1ok) { menu.push_back(make_g1<4, 4, EPI_PLAIN>()); menu.push_back(make_g1<2, 4, EPI_PLAIN>()); } }
+        else if (up == 2) { conv_menu<1, 1, 16, EPI_UP2>(menu); if (g1ok) { menu.push_back(make_g1<4, 4, EPI_UP2>()); menu.push_back(make_g1<8, 4, EPI_UP2>()); } }
+        else { conv_menu<1, 1, 16, EPI_UP4>(menu); if (g1ok) { menu.push_back(make_g1<4, 4, EPI_UP4>()); menu.push_back(make_g1<8, 4, EPI_UP4>()); } }
     } else if (stride == 2) {
         conv_menu<3, 2, 8, EPI_PLAIN>(menu);
     } else {
