@@ -1907,12 +1907,15 @@ void tune_cache_save()
 // Measure every admissible tiling of one layer on the device (1 warm-up + 3 timed launches with
 // hipEvents) and keep the fastest.  Weights are really packed for each candidate, the prologue /
 // statistics epilogue run as in production.
+constexpr int TUNE_FRAMES = 8;          // frames per timed launch of the tuner
+constexpr size_t TUNE_OUT_FS = 0, TUNE_IN_FS = 0; // 0: natural per-frame strides
+
 int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose)
 {
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
     snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d b%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind,
-             ctx->max_batch < 4 ? ctx->max_batch : 4);
+             ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
     std::vector<Variant> menu;
     layer_menu(L.kind, L.stride, L.up, menu, L.cin);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
@@ -1932,7 +1935,9 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     if (L.kind == 2 || (L.kind == 0 && L.stride == 1)) { pre.mode = PRE_AFFINE; pre.scale = net->ones; pre.shift = net->zeros; }
     double* st = (ctx->cfg.norm_kind == 0 && L.kind != 2) ? net->stats + (size_t)23 * NREP * 320 * 2 : nullptr;
     const int stC = (L.kind == 1) ? 320 : L.cout;
-    const int tb = ctx->max_batch < 4 ? ctx->max_batch : 4; // batched like production; frames alias the scratch buffers
+    // batched like production, every frame with its own buffers: a launch then streams more than the 256 MB
+    // Infinity Cache holds, as in production (aliased frames would hide a tiling's HBM re-reads)
+    const int tb = ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES;
     auto time_variant = [&](const Variant& v, int reps, double& out_ms) -> int {
         const size_t need = (v.wino == 3) ? g1_lds(v, L.cin) : v.lds;
         L.var = v;
@@ -1942,7 +1947,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
         float ms = 0.f;
         for (int it = 0; it <= reps; ++it) {
             if (it == 1) PP_HIP(hipEventRecord(e0, 0));
-            rc = launch_conv(ctx, L, tin, Hin, Win, (L.kind == 2) ? ctx->f_cls : tout, nullptr, pre, st, stC, Hout, Wout, 0, ctx->f_box, ctx->f_dir, tb, 4, 4);
+            rc = launch_conv(ctx, L, tin, Hin, Win, (L.kind == 2) ? ctx->f_cls : tout, nullptr, pre, st, stC, Hout, Wout, 0, ctx->f_box, ctx->f_dir, tb, TUNE_OUT_FS, TUNE_IN_FS);
             if (rc) return rc;
         }
         PP_HIP(hipEventRecord(e1, 0));
@@ -2121,9 +2126,10 @@ int pp_net_commit(pp_ctx* ctx)
         const bool can_tune = tune && (H % 4 == 0) && (W % 4 == 0);
         if (can_tune) {
             const size_t nin = std::max((size_t)64 * ctx->gx * ctx->gy, (size_t)320 * H * W);
-            PP_HIP(hipMalloc((void**)&tin, (nin + 256) * sizeof(float)));
-            PP_HIP(hipMalloc((void**)&tout, ((size_t)320 * H * W + 256) * sizeof(float)));
-            hipLaunchKernelGGL(fill_pattern, dim3(2048), dim3(256), 0, 0, tin, nin);
+            const int tb = ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES;
+            PP_HIP(hipMalloc((void**)&tin, ((size_t)tb * nin + 256) * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&tout, ((size_t)tb * 320 * H * W + 256) * sizeof(float)));
+            hipLaunchKernelGGL(fill_pattern, dim3(2048), dim3(256), 0, 0, tin, (size_t)tb * nin);
         }
         for (Layer& L : net->layers) {
             int rc = 0;

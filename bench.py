@@ -29,6 +29,23 @@ import torch
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
+def hbm_traffic(tiling, frames):
+    """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside this process, so the
+    figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    (profiles/r01_hbm_traffic.json, made by tools/profile_round.sh + tools/hbm_traffic.py; FETCH_SIZE doubled per the
+    gfx950 correction of MI355X_MICROARCH.md) -- and only if they were taken for the tiling and batch that ran."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t["tilings"].get(tiling)
+        if e is None or t["frames_per_launch"] != frames:
+            return None, None
+        return int(e["hbm_bytes_per_launch"]), "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def host_cores():
     """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (a GPU box
     gives one GPU's share of the host, 16 CPUs, although 256 are visible)."""
@@ -191,10 +208,17 @@ def main():
                        "cls_bias": args.cls_bias, "mean_detections": float(cnt_h[:, :, 0].float().mean())},
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0
+        traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), NB)
         out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{NB} frames, tiling '{eng.dominant_kernel()}'",
                            "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_ms": round(k_ms, 5), "launches": k_n, "flops_per_launch": k_flops}
+        if eng.dominant_kernel().startswith("wino"):
+            # Winograd F(2x2,3x3) issues 16 MFMA multiplications where the direct form needs 36: `achieved` prices the
+            # ALGORITHMIC (direct-conv) flops and can pass the MFMA peak; `executed` is what the matrix cores really ran
+            out["roofline"]["algorithm"] = "Winograd F(2x2,3x3): executed MFMA flops = algorithmic x 4/9"
+            out["roofline"]["executed"] = round(ach * 4.0 / 9.0, 3)
+            out["roofline"]["executed_frac"] = round(ach * 4.0 / 9.0 / F32_MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, args.cpu_frames)
         print(json.dumps(out), flush=True)

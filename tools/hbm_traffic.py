@@ -1,39 +1,42 @@
-"""HBM traffic per launch of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+"""HBM traffic per launch of the roofline kernel from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, one
+pass each, per forced tiling).
 
-usage: hbm_traffic.py <dir_fetch> <dir_write> <kernel-substring> <out.json> [algorithmic_bytes]
+usage: hbm_traffic.py <out.json> <frames> <algorithmic_bytes> <tiling>=<dir_fetch>,<dir_write> [...]
 
-Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950 FETCH_SIZE tallies
-128-B requests at 64 B for wide coalesced reads, so the corrected figure doubles it (both are written).
+The roofline kernel is the 3x3 s1 64->64 layer at 400x400: of all wino_mfma launches in a pass it has the
+largest grid.  Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950
+FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so the corrected figure doubles it (both
+are written; the kernel reads dwords, for which the guide calls the absolute uncalibrated, so the true read
+side lies between the two).
 """
 import csv, glob, json, sys
 
 
-def avg(d, counter, sub):
+def rows(d, counter):
     f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
-    vals, names = [], set()
-    for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == counter and sub in r['Kernel_Name']:
-            vals.append(float(r['Counter_Value']))
-            names.add(r['Kernel_Name'])
-    if not vals:
-        raise SystemExit(f'no {counter} rows for {sub!r} in {f}')
-    return sum(vals) / len(vals), len(vals), sorted(names)
+    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'wino_mfma' in r['Kernel_Name']]
+    if not rs:
+        raise SystemExit(f'no {counter} rows for wino_mfma in {f}')
+    g = max(int(r['Grid_Size']) for r in rs)
+    rs = [r for r in rs if int(r['Grid_Size']) == g]
+    vals = [float(r['Counter_Value']) for r in rs]
+    return sum(vals) / len(vals), len(vals), rs[0]['Kernel_Name'].replace('(anonymous namespace)::', '')
 
 
-fd, wd, sub, out = sys.argv[1:5]
-alg = float(sys.argv[5]) if len(sys.argv) > 5 else None
-fs, nf, names = avg(fd, 'FETCH_SIZE', sub)
-ws, nw, _ = avg(wd, 'WRITE_SIZE', sub)
-res = {
-    'kernel': names[0].replace('(anonymous namespace)::', ''),
-    'launches_fetch_pass': nf, 'launches_write_pass': nw,
-    'fetch_size_kib_raw': fs, 'write_size_kib': ws,
-    'read_bytes_corrected': 2 * fs * 1024, 'write_bytes': ws * 1024,
-    'hbm_bytes_per_launch': 2 * fs * 1024 + ws * 1024,
-    'hbm_bytes_per_launch_uncorrected': fs * 1024 + ws * 1024,
-    'algorithmic_bytes_per_launch': alg,
-    'note': 'FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads; the kernel reads with dword buffer loads, '
-            'for which the guide calls the absolute uncalibrated -- the true read side lies between the two figures',
-}
+out, frames, alg = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+res = {'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg, 'layer': 'conv 3x3 s1 64->64 @ 400x400',
+       'unit': 'bytes', 'tilings': {}}
+for spec in sys.argv[4:]:
+    name, dirs = spec.split('=')
+    fd, wd = dirs.split(',')
+    fs, nf, kern = rows(fd, 'FETCH_SIZE')
+    ws, nw, _ = rows(wd, 'WRITE_SIZE')
+    res['tilings'][name] = {
+        'kernel': kern, 'launches_fetch_pass': nf, 'launches_write_pass': nw,
+        'fetch_size_kib_raw': fs, 'write_size_kib': ws,
+        'read_bytes_corrected': 2 * fs * 1024, 'write_bytes': ws * 1024,
+        'hbm_bytes_per_launch': 2 * fs * 1024 + ws * 1024,
+        'hbm_bytes_per_launch_uncorrected': fs * 1024 + ws * 1024,
+    }
 json.dump(res, open(out, 'w'), indent=1)
-print(json.dumps(res))
+print(json.dumps(res, indent=1))

@@ -1,0 +1,27 @@
+"""Cross-check of bench.py's event-timed roofline kernel against the rocprofv3 kernel trace of the same run.
+
+usage: roofline_check.py <rocprof_dir> <bench_json_of_that_run>
+
+The roofline kernel (3x3 s1 64->64 at 400x400) shares its template instance with other layers when the tuner
+picks the same tiling for them, so the trace rows are filtered to the launches with the largest grid of that
+symbol (the 400x400 layer) and only the timed steps (the last `launches` of them).
+"""
+import csv, glob, json, sys
+
+d, bj = sys.argv[1], sys.argv[2]
+b = json.loads(open(bj).read().strip().splitlines()[-1])
+r = b['roofline']
+f = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))[-1]
+rows = [x for x in csv.DictReader(open(f)) if 'wino_mfma' in x['Kernel_Name']]
+gs = lambda x: int(x['Grid_Size_X']) * int(x['Grid_Size_Y']) * int(x['Grid_Size_Z'])
+g = max(gs(x) for x in rows)
+rows = [x for x in rows if gs(x) == g]
+rows.sort(key=lambda x: int(x['Start_Timestamp']))
+rows = rows[-r['launches']:]
+dur = [(int(x['End_Timestamp']) - int(x['Start_Timestamp'])) / 1e6 for x in rows]
+avg = sum(dur) / len(dur)
+print(f"kernel            : {rows[0]['Kernel_Name'].replace('(anonymous namespace)::', '')}  grid={g} threads")
+print(f"bench.py          : {r['kernel']}")
+print(f"HIP events (bench): avg {r['avg_launch_ms']:.5f} ms over {r['launches']} launches")
+print(f"rocprofv3 trace   : avg {avg:.5f} ms over {len(dur)} launches (min {min(dur):.5f}, max {max(dur):.5f})")
+print(f"ratio events/trace: {r['avg_launch_ms'] / avg:.4f}")
