@@ -12,7 +12,7 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) occ_mark(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars,
+__device__ __forceinline__ void occ_mark_body(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars,
                                                 int gy, int32_t* __restrict__ occ)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) occ_mark(const int32_t* __restrict__ coor
     atomicAdd(&occ[coors[3 * p] * gy + coors[3 * p + 1]], 1);
 }
 
-__global__ void __launch_bounds__(256) scan_rows(int32_t* __restrict__ occ, int gx, int gy)
+__device__ __forceinline__ void scan_rows_body(int32_t* __restrict__ occ, int gx, int gy)
 {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) scan_rows(int32_t* __restrict__ occ, int 
     }
 }
 
-__global__ void __launch_bounds__(1024) scan_cols(int32_t* __restrict__ occ, int gx, int gy)
+__device__ __forceinline__ void scan_cols_body(int32_t* __restrict__ occ, int gx, int gy)
 {
     __shared__ int part[16][64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(1024) scan_cols(int32_t* __restrict__ occ, int
         }
 }
 
-__global__ void __launch_bounds__(256) mask_lookup_sep(const int32_t* __restrict__ sat, int gy, int H, int W, int types,
+__device__ __forceinline__ void mask_lookup_sep_body(const int32_t* __restrict__ sat, int gy, int H, int W, int types,
                                                        const int32_t* __restrict__ rect_x, const int32_t* __restrict__ rect_y,
                                                        uint8_t* __restrict__ mask)
 {
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) mask_lookup_sep(const int32_t* __restrict
     mask[a] = area > 0;
 }
 
-__global__ void __launch_bounds__(256) mask_lookup_full(const int32_t* __restrict__ sat, int gy, int64_t A,
+__device__ __forceinline__ void mask_lookup_full_body(const int32_t* __restrict__ sat, int gy, int64_t A,
                                                         const int4* __restrict__ rects, uint8_t* __restrict__ mask)
 {
     int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,6 +88,41 @@ __global__ void __launch_bounds__(256) mask_lookup_full(const int32_t* __restric
     int4 r = rects[a]; // minx, miny, maxx, maxy
     int area = sat[r.z * gy + r.w] - sat[r.z * gy + r.y] - sat[r.x * gy + r.w] + sat[r.x * gy + r.y];
     mask[a] = area > 0;
+}
+
+__global__ void __launch_bounds__(256) occ_mark(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy, int32_t* __restrict__ occ)
+{
+    occ_mark_body(coors, num_pillars, gy, occ);
+}
+__global__ void __launch_bounds__(256) scan_rows(int32_t* __restrict__ occ, int gx, int gy) { scan_rows_body(occ, gx, gy); }
+__global__ void __launch_bounds__(1024) scan_cols(int32_t* __restrict__ occ, int gx, int gy) { scan_cols_body(occ, gx, gy); }
+__global__ void __launch_bounds__(256) mask_lookup_sep(const int32_t* __restrict__ sat, int gy, int H, int W, int types,
+                                                       const int32_t* __restrict__ rect_x, const int32_t* __restrict__ rect_y, uint8_t* __restrict__ mask)
+{
+    mask_lookup_sep_body(sat, gy, H, W, types, rect_x, rect_y, mask);
+}
+__global__ void __launch_bounds__(256) mask_lookup_full(const int32_t* __restrict__ sat, int gy, int64_t A, const int4* __restrict__ rects, uint8_t* __restrict__ mask)
+{
+    mask_lookup_full_body(sat, gy, A, rects, mask);
+}
+// batched twins: blockIdx.z = frame
+__global__ void __launch_bounds__(256) occ_mark_b(const pp_pre_frame* __restrict__ tab, int gy)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    occ_mark_body(F.coors, F.num, gy, F.occ);
+}
+__global__ void __launch_bounds__(256) scan_rows_b(const pp_pre_frame* __restrict__ tab, int gx, int gy) { scan_rows_body(tab[blockIdx.z].occ, gx, gy); }
+__global__ void __launch_bounds__(1024) scan_cols_b(const pp_pre_frame* __restrict__ tab, int gx, int gy) { scan_cols_body(tab[blockIdx.z].occ, gx, gy); }
+__global__ void __launch_bounds__(256) mask_lookup_sep_b(const pp_pre_frame* __restrict__ tab, int gy, int H, int W, int types,
+                                                         const int32_t* __restrict__ rect_x, const int32_t* __restrict__ rect_y)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    mask_lookup_sep_body(F.occ, gy, H, W, types, rect_x, rect_y, F.mask);
+}
+__global__ void __launch_bounds__(256) mask_lookup_full_b(const pp_pre_frame* __restrict__ tab, int gy, int64_t A, const int4* __restrict__ rects)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    mask_lookup_full_body(F.occ, gy, A, rects, F.mask);
 }
 
 } // namespace
@@ -115,6 +150,25 @@ int pp_anchor_mask_slot(pp_ctx* ctx, int si, const int32_t* coors, const int32_t
     } else {
         hipLaunchKernelGGL(mask_lookup_full, dim3(pp_div_up(ctx->A, 256)), dim3(256), 0, stream, S.occ, gy, ctx->A,
                            (const int4*)ctx->rects, mask);
+    }
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+// occ tables were zeroed by pre_init_b (voxelize.hip)
+int pp_anchor_mask_group(pp_ctx* ctx, int b0, int g, hipStream_t stream)
+{
+    const pp_pre_frame* tab = ctx->d_pre + b0;
+    const int gx = ctx->gx, gy = ctx->gy;
+    hipLaunchKernelGGL(occ_mark_b, dim3(pp_div_up(ctx->cfg.max_voxels, 256), 1, g), dim3(256), 0, stream, tab, gy);
+    hipLaunchKernelGGL(scan_rows_b, dim3(pp_div_up(gx, 4), 1, g), dim3(256), 0, stream, tab, gx, gy);
+    hipLaunchKernelGGL(scan_cols_b, dim3(pp_div_up(gy, 64), 1, g), dim3(1024), 0, stream, tab, gx, gy);
+    if (ctx->rect_separable) {
+        int types = (int)(ctx->A / ((int64_t)ctx->H * ctx->W));
+        hipLaunchKernelGGL(mask_lookup_sep_b, dim3(pp_div_up(ctx->A, 256), 1, g), dim3(256), 0, stream, tab, gy, ctx->H, ctx->W, types,
+                           ctx->rect_x, ctx->rect_y);
+    } else {
+        hipLaunchKernelGGL(mask_lookup_full_b, dim3(pp_div_up(ctx->A, 256), 1, g), dim3(256), 0, stream, tab, gy, ctx->A, (const int4*)ctx->rects);
     }
     PP_HIP(hipGetLastError());
     return 0;

@@ -594,7 +594,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #pragma unroll
         for (int x = 0; x < 16; ++x) acc[i][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const size_t in_plane = (size_t)p.Hin * p.Win;
     const int nchunk = p.Cin / KC;
 
     float xv[C::PR][KC];
@@ -677,7 +676,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     }
 // row pass for Winograd point XI
 #define WN_ROWPASS(T, XI)                                                                        \
-    (((XI) & 3) == 0 ? T[(XI)] - T[(XI) + 2] : ((XI) & 3) == 1 ? T[(XI)] + T[(XI) + 1] : ((XI) & 3) == 2 ? T[(XI)] - T[(XI) - 1] : T[(XI) - 2] - T[(XI)])
+    (((XI) & 3) == 0 ? T[(XI)] - T[((XI) + 2) & 15] : ((XI) & 3) == 1 ? T[(XI)] + T[((XI) + 1) & 15] : ((XI) & 3) == 2 ? T[(XI)] - T[((XI) - 1) & 15] : T[((XI) - 2) & 15] - T[(XI)]) /* & 15: keeps the untaken arms in range */
 
     constexpr int NQ = KC / 4;
     constexpr int NSTEP = NQ * 16;
@@ -1269,7 +1268,6 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         }
         // N-tile j of this item = pixels {pix0 + 4m + j}: one dwordx4 per lane and step feeds all four tiles
         static_assert(NT == 4, "gemm1x1 is written for 4 interleaved N-tiles");
-        const float* gin = p.in + (size_t)fr * p.in_fs + (size_t)kq * plane;
         const int pxb = pix0 + 4 * m;       // first of this lane's 4 pixels (HW % 4 == 0: all four valid or none)
         const bool pok = pxb < HW;
         const int pof = pok ? pxb : 0;

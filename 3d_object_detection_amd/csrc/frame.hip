@@ -4,6 +4,7 @@
 // the launches get several rounds of workgroups, so the prologue/epilogue of one round overlaps the MFMA
 // phase of the next instead of being exposed once per frame and layer.
 #include <cstdlib>
+#include <cstring>
 #include "pp_common.h"
 
 extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int32_t* n_h, int nb, float* det, int32_t* det_count,
@@ -21,6 +22,31 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
     const size_t cells = (size_t)ctx->gx * ctx->gy;
     const size_t A = (size_t)ctx->A;
     int rc;
+    // PP_BATCH_STAGES=0: the earlier scheme (one launch per stage AND frame, frames dealt round-robin to the
+    // caller's stream plus PP_AUX_STREAMS internal ones) -- kept for A/B timing and as the parity reference of the
+    // batched stage kernels.
+    static const bool batched = !(getenv("PP_BATCH_STAGES") && getenv("PP_BATCH_STAGES")[0] == '0');
+    if (batched) {
+        // The integer stages are latency-bound at one frame per launch (a few workgroups each); with blockIdx.z =
+        // frame every stage is ONE launch per group of <= 16 frames: 21 launches per group instead of 21 per frame.
+        if ((rc = pp_build_tables(ctx))) return rc;
+        for (int b0 = 0; b0 < nb; b0 += PP_GROUP) {
+            const int g = nb - b0 < PP_GROUP ? nb - b0 : PP_GROUP;
+            pp_in_group in;
+            memset(&in, 0, sizeof(in));
+            for (int i = 0; i < g; ++i) { in.pts[i] = pts_h[b0 + i]; in.n[i] = n_h[b0 + i]; }
+            if ((rc = pp_voxelize_group(ctx, b0, g, in, stream))) return rc;
+            if ((rc = pp_anchor_mask_group(ctx, b0, g, stream))) return rc;
+            if ((rc = pp_pfn_pmap_group(ctx, b0, g, stream))) return rc;
+        }
+        if ((rc = pp_run_backbone(ctx, nullptr, nb, stream, ctx->f_pmap, ctx->f_feat))) return rc;
+        if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
+        for (int b0 = 0; b0 < nb; b0 += PP_GROUP) {
+            const int g = nb - b0 < PP_GROUP ? nb - b0 : PP_GROUP;
+            if ((rc = pp_postprocess_group(ctx, b0, g, det, det_count, nms_mode, stream))) return rc;
+        }
+        return 0;
+    }
     // frames are dealt round-robin to (1 + naux) streams: the caller's and naux internal ones.  The GPU exposes
     // 4 hardware queues by default, so more than 3 internal streams only adds queue-switch overhead.
     static const int naux_env = getenv("PP_AUX_STREAMS") ? atoi(getenv("PP_AUX_STREAMS")) : 3;

@@ -16,7 +16,7 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) pfn_kernel(const float* __restrict__ voxels, const int32_t* __restrict__ coors,
+__device__ __forceinline__ void pfn_kernel_body(const float* __restrict__ voxels, const int32_t* __restrict__ coors,
                                                   const int32_t* __restrict__ npts, const int32_t* __restrict__ num_pillars,
                                                   const float* __restrict__ wT /*[9][64]*/, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, float vx, float vy, float x_off,
@@ -80,11 +80,30 @@ __global__ void __launch_bounds__(256) scatter_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(256) pmap_kernel(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy,
+__device__ __forceinline__ void pmap_kernel_body(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy,
                                                    int32_t* __restrict__ pmap)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < *num_pillars) pmap[(size_t)coors[3 * p] * gy + coors[3 * p + 1]] = p;
+}
+
+__global__ void __launch_bounds__(256) pfn_kernel(const float* __restrict__ voxels, const int32_t* __restrict__ coors, const int32_t* __restrict__ npts,
+                                                  const int32_t* __restrict__ num_pillars, const float* __restrict__ wT, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, float vx, float vy, float x_off, float y_off, int T, float* __restrict__ feat)
+{
+    pfn_kernel_body(voxels, coors, npts, num_pillars, wT, scale, shift, vx, vy, x_off, y_off, T, feat);
+}
+__global__ void __launch_bounds__(256) pmap_kernel(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy, int32_t* __restrict__ pmap)
+{
+    pmap_kernel_body(coors, num_pillars, gy, pmap);
+}
+// batched twin: PFN rows and the pillar map of frame blockIdx.z in one launch (the map was filled with -1 by pre_init_b)
+__global__ void __launch_bounds__(256) pfn_pmap_b(const pp_pre_frame* __restrict__ tab, const float* __restrict__ wT, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, float vx, float vy, float x_off, float y_off, int T, int gy, int pmap_blocks)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    pfn_kernel_body(F.voxels, F.coors, F.npts, F.num, wT, scale, shift, vx, vy, x_off, y_off, T, F.feat);
+    if ((int)blockIdx.x < pmap_blocks) pmap_kernel_body(F.coors, F.num, gy, F.pmap);
 }
 
 } // namespace
@@ -125,6 +144,20 @@ extern "C" int pp_scatter(pp_ctx* ctx, const float* feat, const int32_t* coors, 
     size_t plane = (size_t)ctx->gx * ctx->gy;
     PP_HIP(hipMemsetAsync(canvas, 0, plane * 64 * sizeof(float), stream));
     hipLaunchKernelGGL(scatter_kernel, dim3(1024), dim3(256), 0, stream, feat, coors, num_pillars, ctx->gy, plane, canvas);
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pp_pfn_pmap_group(pp_ctx* ctx, int b0, int g, hipStream_t stream)
+{
+    if (ctx->cfg.num_point_features != 4) return pp_fail(ctx, PP_E_ARG, "pp_pfn: only F=4 point features supported");
+    const pp_config& c = ctx->cfg;
+    const float vx = c.voxel_size[0], vy = c.voxel_size[1];
+    const float x_off = vx / 2 + c.offset[0], y_off = vy / 2 + c.offset[1]; // :18-19
+    const int pmap_blocks = pp_div_up(c.max_voxels, 256);
+    const int blocks = pmap_blocks > 256 ? pmap_blocks : 256;
+    hipLaunchKernelGGL(pfn_pmap_b, dim3(blocks, 1, g), dim3(256), 0, stream, ctx->d_pre + b0, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift, vx, vy,
+                       x_off, y_off, c.max_num_points, ctx->gy, pmap_blocks);
     PP_HIP(hipGetLastError());
     return 0;
 }

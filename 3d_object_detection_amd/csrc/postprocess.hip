@@ -49,7 +49,7 @@ __device__ __forceinline__ float sigmoid_rn(float x)
 
 // ---------------------------------------------------------------- Q1
 constexpr int FILTER_ITEMS = 8; // anchors per thread
-__global__ void __launch_bounds__(256) post_filter(const float* __restrict__ cls, const uint8_t* __restrict__ mask, pp_config cfg,
+__device__ __forceinline__ void post_filter_body(const float* __restrict__ cls, const uint8_t* __restrict__ mask, pp_config cfg,
                                                    float thr, uint32_t thr_bits, int bin_shift, int64_t cand_cap,
                                                    uint64_t* __restrict__ cand, int32_t* __restrict__ counters,
                                                    int32_t* __restrict__ hist)
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) post_filter(const float* __restrict__ cls
 }
 
 // ---------------------------------------------------------------- Q2
-__global__ void __launch_bounds__(1024) post_thresh(const int32_t* __restrict__ hist, int32_t* __restrict__ counters, int K)
+__device__ __forceinline__ void post_thresh_body(const int32_t* __restrict__ hist, int32_t* __restrict__ counters, int K)
 {
     __shared__ int part[1024];
     const int c = blockIdx.x, t = threadIdx.x;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(1024) post_thresh(const int32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- Q3
-__global__ void __launch_bounds__(256) post_gather(const uint64_t* __restrict__ cand, int64_t cand_cap, int32_t* __restrict__ counters,
+__device__ __forceinline__ void post_gather_body(const uint64_t* __restrict__ cand, int64_t cand_cap, int32_t* __restrict__ counters,
                                                    uint32_t thr_bits, int bin_shift, uint64_t* __restrict__ shortl)
 {
     const int c = blockIdx.y;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void standup_box(float cx, float cy, float dx, float 
 }
 
 // ---------------------------------------------------------------- Q4
-__global__ void __launch_bounds__(1024) post_topk(pp_config cfg, const uint64_t* __restrict__ cand, int64_t cand_cap,
+__device__ __forceinline__ void post_topk_body(pp_config cfg, const uint64_t* __restrict__ cand, int64_t cand_cap,
                                                   const uint64_t* __restrict__ shortl, int32_t* __restrict__ counters, int K,
                                                   const float* __restrict__ box, const float* __restrict__ dir,
                                                   const float* __restrict__ anchors, int rotate, uint64_t* __restrict__ sel,
@@ -379,10 +379,9 @@ __device__ float rotated_iou_dev(const float* r1, const float* r2)
 // TRANSPOSED suppression mask, row-tile major: maskT[rt][col] holds, for column box `col`, the bits r of the row boxes
 // (rt*64 + r) that suppress it (IoU > thr and row < col).  One wave per (col tile, row tile); the lane owning a
 // column accumulates its own word while the row boxes are broadcast with readlane -- no ballot, no loads in the loop.
-__global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, int nstride, const int32_t* __restrict__ nsel_p,
+__device__ __forceinline__ void nms_mask_body(const int c, const float* __restrict__ nbox, int nstride, const int32_t* __restrict__ nsel_p,
                                                int nsel_stride, int K, int cb, float thr, int rotate, uint64_t* __restrict__ maskT)
 {
-    const int c = blockIdx.z;
     const int n = nsel_p[c * nsel_stride];
     const int ct = blockIdx.x, rt = blockIdx.y;
     if (ct < rt || rt * 64 >= n || ct * 64 >= n) return;
@@ -457,7 +456,7 @@ __device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int K,
 }
 
 // ---------------------------------------------------------------- Q6
-__global__ void __launch_bounds__(512) nms_reduce(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
+__device__ __forceinline__ void nms_reduce_body(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
                                                   const float* __restrict__ boxes, const int32_t* __restrict__ dirl,
                                                   int32_t* __restrict__ counters, int K, int cb, int32_t* __restrict__ keep_ws,
                                                   float* __restrict__ det, int32_t* __restrict__ det_count)
@@ -521,6 +520,82 @@ int shift_for(uint32_t thr_bits)
     int s = 0;
     while ((range >> s) >= (uint32_t)NBINS) ++s;
     return s;
+}
+
+// ---- single-frame entry kernels and their batched twins (blockIdx.z = frame; nms_mask: z = frame * ncls + class) ----
+__global__ void __launch_bounds__(256) post_filter(const float* __restrict__ cls, const uint8_t* __restrict__ mask, pp_config cfg, float thr,
+                                                   uint32_t thr_bits, int bin_shift, int64_t cand_cap, uint64_t* __restrict__ cand,
+                                                   int32_t* __restrict__ counters, int32_t* __restrict__ hist)
+{
+    post_filter_body(cls, mask, cfg, thr, thr_bits, bin_shift, cand_cap, cand, counters, hist);
+}
+__global__ void __launch_bounds__(1024) post_thresh(const int32_t* __restrict__ hist, int32_t* __restrict__ counters, int K)
+{
+    post_thresh_body(hist, counters, K);
+}
+__global__ void __launch_bounds__(256) post_gather(const uint64_t* __restrict__ cand, int64_t cand_cap, int32_t* __restrict__ counters,
+                                                   uint32_t thr_bits, int bin_shift, uint64_t* __restrict__ shortl)
+{
+    post_gather_body(cand, cand_cap, counters, thr_bits, bin_shift, shortl);
+}
+__global__ void __launch_bounds__(1024) post_topk(pp_config cfg, const uint64_t* __restrict__ cand, int64_t cand_cap, const uint64_t* __restrict__ shortl,
+                                                  int32_t* __restrict__ counters, int K, const float* __restrict__ box, const float* __restrict__ dir,
+                                                  const float* __restrict__ anchors, int nms_mode, uint64_t* __restrict__ sel,
+                                                  float* __restrict__ boxes, float* __restrict__ nbox, int32_t* __restrict__ dirl)
+{
+    post_topk_body(cfg, cand, cand_cap, shortl, counters, K, box, dir, anchors, nms_mode, sel, boxes, nbox, dirl);
+}
+__global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, int nstride, const int32_t* __restrict__ nsel_p, int nsel_stride,
+                                               int K, int cb, float thr, int rotate, uint64_t* __restrict__ maskT)
+{
+    nms_mask_body(blockIdx.z, nbox, nstride, nsel_p, nsel_stride, K, cb, thr, rotate, maskT);
+}
+__global__ void __launch_bounds__(512) nms_reduce(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
+                                                  const float* __restrict__ boxes, const int32_t* __restrict__ dirl, int32_t* __restrict__ counters,
+                                                  int K, int cb, int32_t* __restrict__ keep_ws, float* __restrict__ det, int32_t* __restrict__ det_count)
+{
+    nms_reduce_body(cfg, mask, sel, boxes, dirl, counters, K, cb, keep_ws, det, det_count);
+}
+
+__global__ void __launch_bounds__(256) post_init_b(const pp_post_frame* __restrict__ tab, int nwords)
+{
+    int32_t* h = tab[blockIdx.z].hist; // hist | counters are one allocation
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) h[i] = 0;
+}
+__global__ void __launch_bounds__(256) post_filter_b(const pp_post_frame* __restrict__ tab, pp_config cfg, float thr, uint32_t thr_bits,
+                                                     int bin_shift, int64_t cand_cap)
+{
+    const pp_post_frame F = tab[blockIdx.z];
+    post_filter_body(F.cls, F.mask, cfg, thr, thr_bits, bin_shift, cand_cap, F.cand, F.counters, F.hist);
+}
+__global__ void __launch_bounds__(1024) post_thresh_b(const pp_post_frame* __restrict__ tab, int K)
+{
+    const pp_post_frame F = tab[blockIdx.z];
+    post_thresh_body(F.hist, F.counters, K);
+}
+__global__ void __launch_bounds__(256) post_gather_b(const pp_post_frame* __restrict__ tab, int64_t cand_cap, uint32_t thr_bits, int bin_shift)
+{
+    const pp_post_frame F = tab[blockIdx.z];
+    post_gather_body(F.cand, cand_cap, F.counters, thr_bits, bin_shift, F.shortl);
+}
+__global__ void __launch_bounds__(1024) post_topk_b(const pp_post_frame* __restrict__ tab, pp_config cfg, int64_t cand_cap, int K,
+                                                    const float* __restrict__ anchors, int nms_mode)
+{
+    const pp_post_frame F = tab[blockIdx.z];
+    post_topk_body(cfg, F.cand, cand_cap, F.shortl, F.counters, K, F.box, F.dir, anchors, nms_mode, F.sel, F.boxes, F.nbox, F.dirl);
+}
+__global__ void __launch_bounds__(64) nms_mask_b(const pp_post_frame* __restrict__ tab, int ncls, int K, int cb, float thr, int rotate)
+{
+    const int fr = blockIdx.z / ncls, c = blockIdx.z - fr * ncls;
+    const pp_post_frame F = tab[fr];
+    nms_mask_body(c, F.nbox, 6, F.counters + 3, 8, K, cb, thr, rotate, F.nmask);
+}
+__global__ void __launch_bounds__(512) nms_reduce_b(const pp_post_frame* __restrict__ tab, pp_config cfg, int K, int cb, float* __restrict__ det,
+                                                    size_t det_fs, int32_t* __restrict__ det_count, int cnt_fs)
+{
+    const pp_post_frame F = tab[blockIdx.z];
+    nms_reduce_body(cfg, F.nmask, F.sel, F.boxes, F.dirl, F.counters, K, cb, F.dirl + (size_t)cfg.num_classes * K, det + blockIdx.z * det_fs,
+                    det_count + blockIdx.z * cnt_fs);
 }
 
 } // namespace
@@ -607,6 +682,37 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
                        c.nms_iou_threshold, nms_mode, P->nmask);
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(512), 0, stream, c, P->nmask, P->sel, P->boxes, P->dirl, P->counters, P->K, P->cb,
                        P->dirl + (size_t)n * P->K, det, det_count);
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+void pp_post_fill_table(pp_ctx* ctx, int slot, pp_post_frame* f)
+{
+    const pp_post* P = (const pp_post*)ctx->slot[slot].post;
+    f->cand = P->cand; f->shortl = P->shortl; f->sel = P->sel; f->nmask = P->nmask;
+    f->counters = P->counters; f->hist = P->hist; f->dirl = P->dirl;
+    f->boxes = P->boxes; f->nbox = P->nbox;
+}
+
+// post-processing of frames b0 .. b0+g-1 as one launch per stage (blockIdx.z = frame)
+int pp_postprocess_group(pp_ctx* ctx, int b0, int g, float* det, int32_t* det_count, int nms_mode, hipStream_t stream)
+{
+    const pp_post* P = (const pp_post*)ctx->slot[0].post; // sizes are the same for every slot
+    const pp_config& c = ctx->cfg;
+    const int n = c.num_classes;
+    for (int i = 0; i < n; ++i)
+        if (c.class_end[i] > ctx->A) return pp_fail(ctx, PP_E_ARG, "class range exceeds anchor count");
+    const pp_post_frame* tab = ctx->d_post + b0;
+    const size_t det_fs = (size_t)n * c.nms_post_max * 9;
+    hipLaunchKernelGGL(post_init_b, dim3(8, 1, g), dim3(256), 0, stream, tab, n * (NBINS + 8));
+    hipLaunchKernelGGL(post_filter_b, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n, g), dim3(256), 0, stream, tab, c, c.score_threshold,
+                       P->thr_bits, P->bin_shift, P->cand_cap);
+    hipLaunchKernelGGL(post_thresh_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, P->K);
+    hipLaunchKernelGGL(post_gather_b, dim3(pp_div_up(P->cand_cap, 256), n, g), dim3(256), 0, stream, tab, P->cand_cap, P->thr_bits, P->bin_shift);
+    hipLaunchKernelGGL(post_topk_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, c, P->cand_cap, P->K, ctx->anchors, nms_mode);
+    hipLaunchKernelGGL(nms_mask_b, dim3(P->cb, P->cb, n * g), dim3(64), 0, stream, tab, n, P->K, P->cb, c.nms_iou_threshold, nms_mode);
+    hipLaunchKernelGGL(nms_reduce_b, dim3(1, 1, g), dim3(512), 0, stream, tab, c, P->K, P->cb, det + (size_t)b0 * det_fs, det_fs,
+                       det_count + (size_t)b0 * PP_DET_COUNT_STRIDE, (int)PP_DET_COUNT_STRIDE);
     PP_HIP(hipGetLastError());
     return 0;
 }

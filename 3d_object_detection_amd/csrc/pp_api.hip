@@ -52,6 +52,8 @@ static int create_impl(pp_ctx* ctx)
         PP_HIP(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
         PP_HIP(hipEventCreateWithFlags(&S.ev_post, hipEventDisableTiming));
     }
+    PP_HIP(hipMalloc((void**)&ctx->d_pre, sizeof(pp_pre_frame) * ctx->max_batch));
+    PP_HIP(hipMalloc((void**)&ctx->d_post, sizeof(pp_post_frame) * ctx->max_batch));
     PP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     PP_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
     PP_HIP(dalloc(&ctx->pfn_w, 9 * 64));
@@ -111,6 +113,40 @@ extern "C" pp_ctx* pp_create(int device, const pp_config* cfg)
     return ctx;
 }
 
+// Device tables of the per-frame buffers the batched integer stages index with blockIdx.z.  The mask / head
+// pointers depend on the anchor count, so the tables are (re)built on the first batch after pp_set_anchors.
+int pp_build_tables(pp_ctx* ctx)
+{
+    if (ctx->tab_A == ctx->A) return 0;
+    const pp_config& c = ctx->cfg;
+    const size_t mv = (size_t)c.max_voxels;
+    const size_t vs = mv * c.max_num_points * c.num_point_features;
+    const size_t cells = (size_t)ctx->gx * ctx->gy;
+    const size_t A = (size_t)ctx->A;
+    std::vector<pp_pre_frame> pre(ctx->max_batch);
+    std::vector<pp_post_frame> post(ctx->max_batch);
+    for (int b = 0; b < ctx->max_batch; ++b) {
+        const pp_slot& S = ctx->slot[b];
+        pp_pre_frame& f = pre[b];
+        f.pt_cell = S.pt_cell; f.cell_first = S.cell_first; f.wave_cnt = S.wave_cnt; f.pt_rank = S.pt_rank;
+        f.slots = S.slots; f.scalars = S.vox_scalars; f.occ = S.occ;
+        f.voxels = ctx->f_voxels + b * vs;
+        f.coors = ctx->f_coors + b * mv * 3;
+        f.npts = ctx->f_npts + b * mv;
+        f.num = ctx->f_num + b * 4;
+        f.mask = ctx->f_mask + b * A;
+        f.feat = ctx->f_feat + b * mv * 64;
+        f.pmap = ctx->f_pmap + b * cells;
+        pp_post_frame& q = post[b];
+        q.cls = ctx->f_cls + b * A; q.box = ctx->f_box + b * A * 7; q.dir = ctx->f_dir + b * A * 2; q.mask = f.mask;
+        pp_post_fill_table(ctx, b, &q);
+    }
+    PP_HIP(hipMemcpy(ctx->d_pre, pre.data(), sizeof(pp_pre_frame) * pre.size(), hipMemcpyHostToDevice));
+    PP_HIP(hipMemcpy(ctx->d_post, post.data(), sizeof(pp_post_frame) * post.size(), hipMemcpyHostToDevice));
+    ctx->tab_A = ctx->A;
+    return 0;
+}
+
 extern "C" void pp_destroy(pp_ctx* ctx)
 {
     if (!ctx) return;
@@ -125,6 +161,8 @@ extern "C" void pp_destroy(pp_ctx* ctx)
         if (S.ev_pre) (void)hipEventDestroy(S.ev_pre);
         if (S.ev_post) (void)hipEventDestroy(S.ev_post);
     }
+    if (ctx->d_pre) (void)hipFree(ctx->d_pre);
+    if (ctx->d_post) (void)hipFree(ctx->d_post);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     void* ptrs[] = {ctx->anchors, ctx->rect_x, ctx->rect_y, ctx->rects, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift,

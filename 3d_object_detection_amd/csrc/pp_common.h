@@ -15,6 +15,30 @@
         if (e_ != hipSuccess) return pp_fail_hip(ctx, e_, #call, __FILE__, __LINE__); \
     } while (0)
 
+// ---- frame tables of the batched integer stages (pp_infer_batch) ---------------------------------
+// The voxeliser / mask / PFN / post-processing kernels of a batch run as ONE launch per stage with
+// blockIdx.z = frame; each frame's buffers are looked up in a device-resident table built once.
+struct pp_pre_frame {
+    int32_t *pt_cell, *cell_first, *wave_cnt, *pt_rank, *slots, *scalars, *occ;
+    float* voxels;
+    int32_t *coors, *npts, *num;
+    uint8_t* mask;
+    float* feat;
+    int32_t* pmap;
+};
+struct pp_post_frame {
+    const float *cls, *box, *dir;
+    const uint8_t* mask;
+    uint64_t *cand, *shortl, *sel, *nmask;
+    int32_t *counters, *hist, *dirl;
+    float *boxes, *nbox;
+};
+#define PP_GROUP 16 // frames per batched launch of the integer stages (kernel-argument table size)
+struct pp_in_group {
+    const float* pts[PP_GROUP];
+    int32_t n[PP_GROUP];
+};
+
 struct pp_tensor_h {
     std::vector<int64_t> shape;
     std::vector<float> data;
@@ -55,6 +79,9 @@ struct pp_ctx {
     //      voxelise / mask / post-processing can run concurrently on internal streams ----
     std::vector<pp_slot> slot;     // [max_batch]; the single-stage entry points use slot 0
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr;
+    pp_pre_frame* d_pre = nullptr;   // [max_batch] device tables (built by pp_build_tables for the current anchor count)
+    pp_post_frame* d_post = nullptr;
+    int64_t tab_A = -1;
     float* anchors = nullptr;      // [A,7]
     int32_t* rect_x = nullptr;     // separable cell rectangles: [types, H, 2] (minx,maxx) / [types, W, 2] (miny,maxy)
     int32_t* rect_y = nullptr;
@@ -95,6 +122,13 @@ int pp_postprocess_slot(pp_ctx* ctx, int s, const float* cls, const float* box, 
 // nb canvases (or, when pmap != nullptr, nb sparse BEV inputs: pillar-index maps + PFN rows) -> pre-norm [nb,320,H,W] + stats
 int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream, const int32_t* pmap, const float* feat);
 int pp_pillar_map(pp_ctx* ctx, const int32_t* coors, const int32_t* num_pillars, int32_t* pmap, hipStream_t stream);
+// batched integer stages: frames b0 .. b0+g-1 of a batch, one launch per stage (blockIdx.z = frame)
+int pp_build_tables(pp_ctx* ctx);
+void pp_post_fill_table(pp_ctx* ctx, int slot, pp_post_frame* f);
+int pp_voxelize_group(pp_ctx* ctx, int b0, int g, const pp_in_group& in, hipStream_t stream);
+int pp_anchor_mask_group(pp_ctx* ctx, int b0, int g, hipStream_t stream);
+int pp_pfn_pmap_group(pp_ctx* ctx, int b0, int g, hipStream_t stream);
+int pp_postprocess_group(pp_ctx* ctx, int b0, int g, float* det, int32_t* det_count, int nms_mode, hipStream_t stream);
 int pp_run_head_fused(pp_ctx* ctx, float* cls, float* box, float* dir, int nb, hipStream_t stream); // norm+ReLU fused in the prologue
 void pp_post_destroy(pp_ctx* ctx);
 

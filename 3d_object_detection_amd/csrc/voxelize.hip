@@ -32,7 +32,7 @@ __device__ __forceinline__ int cell_of(const float* __restrict__ p, float ox, fl
     return (cx * gy + cy) * gz + cz;
 }
 
-__global__ void __launch_bounds__(256) vox_cell_first(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+__device__ __forceinline__ void vox_cell_first_body(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
                                                       int32_t* __restrict__ pt_cell, int32_t* __restrict__ cell_first)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) vox_cell_first(const float* __restrict__ 
     if (c >= 0) atomicMin(&cell_first[c], i);
 }
 
-__global__ void __launch_bounds__(256) vox_flag_count(const int32_t* __restrict__ pt_cell,
+__device__ __forceinline__ void vox_flag_count_body(const int32_t* __restrict__ pt_cell,
                                                       const int32_t* __restrict__ cell_first, int n,
                                                       int32_t* __restrict__ wave_cnt)
 {
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) vox_flag_count(const int32_t* __restrict_
 
 // Each wave derives its own exclusive offset by summing the counts of all earlier waves
 // (nw <= a few thousand: cheaper than a separate scan launch).
-__global__ void __launch_bounds__(256) vox_rank(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+__device__ __forceinline__ void vox_rank_body(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
                                                 const int32_t* __restrict__ pt_cell,
                                                 const int32_t* __restrict__ cell_first,
                                                 const int32_t* __restrict__ wave_cnt, int32_t* __restrict__ pt_rank,
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) vox_rank(const float* __restrict__ pts, i
     }
 }
 
-__global__ void __launch_bounds__(256) vox_insert(int n, pp_config cfg, const int32_t* __restrict__ pt_cell,
+__device__ __forceinline__ void vox_insert_body(int n, pp_config cfg, const int32_t* __restrict__ pt_cell,
                                                   const int32_t* __restrict__ cell_first,
                                                   const int32_t* __restrict__ pt_rank,
                                                   const int32_t* __restrict__ scalars, int32_t* __restrict__ slots)
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) vox_insert(int n, pp_config cfg, const in
     }
 }
 
-__global__ void __launch_bounds__(256) vox_gather(const float* __restrict__ pts, int nfeat, pp_config cfg,
+__device__ __forceinline__ void vox_gather_body(const float* __restrict__ pts, int nfeat, pp_config cfg,
                                                   const int32_t* __restrict__ slots,
                                                   const int32_t* __restrict__ num_pillars, float* __restrict__ voxels,
                                                   int32_t* __restrict__ npts)
@@ -151,6 +151,72 @@ __global__ void __launch_bounds__(256) vox_gather(const float* __restrict__ pts,
         for (int q = 0; q < T; ++q) cnt += slots[(size_t)p * T + q] < PP_EMPTY;
         npts[p] = cnt;
     }
+}
+
+// ---- single-frame entry kernels and their batched twins (blockIdx.z = frame, buffers from the frame table) ----
+__global__ void __launch_bounds__(256) vox_cell_first(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+                                                      int32_t* __restrict__ pt_cell, int32_t* __restrict__ cell_first)
+{
+    vox_cell_first_body(pts, n, nfeat, cfg, pt_cell, cell_first);
+}
+__global__ void __launch_bounds__(256) vox_flag_count(const int32_t* __restrict__ pt_cell, const int32_t* __restrict__ cell_first, int n,
+                                                      int32_t* __restrict__ wave_cnt)
+{
+    vox_flag_count_body(pt_cell, cell_first, n, wave_cnt);
+}
+__global__ void __launch_bounds__(256) vox_rank(const float* __restrict__ pts, int n, int nfeat, pp_config cfg,
+                                                const int32_t* __restrict__ pt_cell, const int32_t* __restrict__ cell_first,
+                                                const int32_t* __restrict__ wave_cnt, int32_t* __restrict__ pt_rank,
+                                                int32_t* __restrict__ coors, int32_t* __restrict__ scalars, int32_t* __restrict__ num_pillars)
+{
+    vox_rank_body(pts, n, nfeat, cfg, pt_cell, cell_first, wave_cnt, pt_rank, coors, scalars, num_pillars);
+}
+__global__ void __launch_bounds__(256) vox_insert(int n, pp_config cfg, const int32_t* __restrict__ pt_cell,
+                                                  const int32_t* __restrict__ cell_first, const int32_t* __restrict__ pt_rank,
+                                                  const int32_t* __restrict__ scalars, int32_t* __restrict__ slots)
+{
+    vox_insert_body(n, cfg, pt_cell, cell_first, pt_rank, scalars, slots);
+}
+__global__ void __launch_bounds__(256) vox_gather(const float* __restrict__ pts, int nfeat, pp_config cfg, const int32_t* __restrict__ slots,
+                                                  const int32_t* __restrict__ num_pillars, float* __restrict__ voxels, int32_t* __restrict__ npts)
+{
+    vox_gather_body(pts, nfeat, cfg, slots, num_pillars, voxels, npts);
+}
+
+// one fill for everything the integer stages of a frame need initialised: cell_first | slots | scalars (0x7F..),
+// the occupancy table (0) and the pillar map (-1)
+__global__ void __launch_bounds__(256) pre_init_b(const pp_pre_frame* __restrict__ tab, int n7f, int nocc, int npmap)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n7f; i += stride) F.cell_first[i] = PP_EMPTY;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nocc; i += stride) F.occ[i] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npmap; i += stride) F.pmap[i] = -1;
+}
+__global__ void __launch_bounds__(256) vox_cell_first_b(pp_in_group in, const pp_pre_frame* __restrict__ tab, int nfeat, pp_config cfg)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    vox_cell_first_body(in.pts[blockIdx.z], in.n[blockIdx.z], nfeat, cfg, F.pt_cell, F.cell_first);
+}
+__global__ void __launch_bounds__(256) vox_flag_count_b(pp_in_group in, const pp_pre_frame* __restrict__ tab)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    vox_flag_count_body(F.pt_cell, F.cell_first, in.n[blockIdx.z], F.wave_cnt);
+}
+__global__ void __launch_bounds__(256) vox_rank_b(pp_in_group in, const pp_pre_frame* __restrict__ tab, int nfeat, pp_config cfg)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    vox_rank_body(in.pts[blockIdx.z], in.n[blockIdx.z], nfeat, cfg, F.pt_cell, F.cell_first, F.wave_cnt, F.pt_rank, F.coors, F.scalars, F.num);
+}
+__global__ void __launch_bounds__(256) vox_insert_b(pp_in_group in, const pp_pre_frame* __restrict__ tab, pp_config cfg)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    vox_insert_body(in.n[blockIdx.z], cfg, F.pt_cell, F.cell_first, F.pt_rank, F.scalars, F.slots);
+}
+__global__ void __launch_bounds__(256) vox_gather_b(pp_in_group in, const pp_pre_frame* __restrict__ tab, int nfeat, pp_config cfg)
+{
+    const pp_pre_frame F = tab[blockIdx.z];
+    vox_gather_body(in.pts[blockIdx.z], nfeat, cfg, F.slots, F.num, F.voxels, F.npts);
 }
 
 } // namespace
@@ -187,6 +253,32 @@ int pp_voxelize_slot(pp_ctx* ctx, int si, const float* pts, int n, int nfeat, fl
     int nt = cfg.max_voxels * cfg.max_num_points;
     hipLaunchKernelGGL(vox_gather, dim3(pp_div_up(nt, 256)), dim3(256), 0, stream, pts, nfeat, cfg, S.slots, num_pillars,
                        voxels, npts);
+    PP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pp_voxelize_group(pp_ctx* ctx, int b0, int g, const pp_in_group& in, hipStream_t stream)
+{
+    const pp_config& cfg = ctx->cfg;
+    int nmax = 0;
+    for (int i = 0; i < g; ++i) {
+        if (in.n[i] < 0 || in.n[i] > cfg.max_points) return pp_fail(ctx, PP_E_ARG, "pp_infer_batch: n exceeds cfg.max_points");
+        if (in.n[i] > 0 && !in.pts[i]) return pp_fail(ctx, PP_E_ARG, "pp_infer_batch: null point cloud");
+        nmax = in.n[i] > nmax ? in.n[i] : nmax;
+    }
+    const pp_pre_frame* tab = ctx->d_pre + b0;
+    const int nfeat = cfg.num_point_features;
+    const size_t cells = (size_t)cfg.grid_size[0] * cfg.grid_size[1] * cfg.grid_size[2];
+    const int n7f = (int)(cells + (size_t)cfg.max_voxels * cfg.max_num_points + 4);
+    const int nbev = ctx->gx * ctx->gy;
+    hipLaunchKernelGGL(pre_init_b, dim3(256, 1, g), dim3(256), 0, stream, tab, n7f, nbev, nbev);
+    const int nb = pp_div_up(nmax > 0 ? nmax : 1, 256);
+    hipLaunchKernelGGL(vox_cell_first_b, dim3(nb, 1, g), dim3(256), 0, stream, in, tab, nfeat, cfg);
+    hipLaunchKernelGGL(vox_flag_count_b, dim3(nb, 1, g), dim3(256), 0, stream, in, tab);
+    hipLaunchKernelGGL(vox_rank_b, dim3(nb, 1, g), dim3(256), 0, stream, in, tab, nfeat, cfg);
+    hipLaunchKernelGGL(vox_insert_b, dim3(nb, 1, g), dim3(256), 0, stream, in, tab, cfg);
+    const int nt = cfg.max_voxels * cfg.max_num_points;
+    hipLaunchKernelGGL(vox_gather_b, dim3(pp_div_up(nt, 256), 1, g), dim3(256), 0, stream, in, tab, nfeat, cfg);
     PP_HIP(hipGetLastError());
     return 0;
 }
