@@ -141,20 +141,49 @@ __device__ __forceinline__ void post_thresh_body(const int32_t* __restrict__ his
 }
 
 // ---------------------------------------------------------------- Q3
+constexpr int GATHER_ITEMS = 16; // candidates per thread
 __device__ __forceinline__ void post_gather_body(const uint64_t* __restrict__ cand, int64_t cand_cap, int32_t* __restrict__ counters,
                                                    uint32_t thr_bits, int bin_shift, uint64_t* __restrict__ shortl)
 {
-    const int c = blockIdx.y;
+    // A workgroup scans 4096 candidates, collects the few that reach the threshold bin in LDS and appends them with
+    // ONE returning global atomic: per-key appends put thousands of returning atomics on one counter word (and the
+    // counters of the frames of a batch share an L2 channel, so they did not even run in parallel across frames).
+    __shared__ uint64_t lbuf[1024];
+    __shared__ int lcnt, gbase;
+    const int c = blockIdx.y, tid = threadIdx.x;
     int n = counters[c * 8 + 0];
     n = n < cand_cap ? n : (int)cand_cap;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = cand[(size_t)c * cand_cap + i];
-    int bin = (int)(((uint32_t)(key >> 32) - thr_bits) >> bin_shift);
-    bin = bin < NBINS ? bin : NBINS - 1;
-    if (bin < counters[c * 8 + 2]) return;
-    const int slot = atomicAdd(&counters[c * 8 + 1], 1);
-    if (slot < SHORT_CAP) shortl[(size_t)c * SHORT_CAP + slot] = key;
+    const int base = blockIdx.x * (256 * GATHER_ITEMS);
+    if (base >= n) return; // workgroup-uniform
+    const int thr_bin = counters[c * 8 + 2];
+    if (tid == 0) lcnt = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < GATHER_ITEMS; ++it) {
+        const int i = base + it * 256 + tid;
+        if (i < n) {
+            const uint64_t key = cand[(size_t)c * cand_cap + i];
+            int bin = (int)(((uint32_t)(key >> 32) - thr_bits) >> bin_shift);
+            bin = bin < NBINS ? bin : NBINS - 1;
+            if (bin >= thr_bin) {
+                const int s = atomicAdd(&lcnt, 1);
+                if (s < 1024) {
+                    lbuf[s] = key;
+                } else { // more than a quarter of the block selected: append directly
+                    const int slot = atomicAdd(&counters[c * 8 + 1], 1);
+                    if (slot < SHORT_CAP) shortl[(size_t)c * SHORT_CAP + slot] = key;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int m = lcnt < 1024 ? lcnt : 1024;
+    if (tid == 0 && m > 0) gbase = atomicAdd(&counters[c * 8 + 1], m);
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+        const int slot = gbase + j;
+        if (slot < SHORT_CAP) shortl[(size_t)c * SHORT_CAP + slot] = lbuf[j];
+    }
 }
 
 // in-LDS bitonic sort, DESCENDING, n2 = power of two
@@ -674,7 +703,7 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
     hipLaunchKernelGGL(post_filter, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n), dim3(256), 0, stream, cls, mask, c, c.score_threshold,
                        P->thr_bits, P->bin_shift, P->cand_cap, P->cand, P->counters, P->hist);
     hipLaunchKernelGGL(post_thresh, dim3(n), dim3(1024), 0, stream, P->hist, P->counters, P->K);
-    hipLaunchKernelGGL(post_gather, dim3(pp_div_up(P->cand_cap, 256), n), dim3(256), 0, stream, P->cand, P->cand_cap, P->counters,
+    hipLaunchKernelGGL(post_gather, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n), dim3(256), 0, stream, P->cand, P->cand_cap, P->counters,
                        P->thr_bits, P->bin_shift, P->shortl);
     hipLaunchKernelGGL(post_topk, dim3(n), dim3(1024), 0, stream, c, P->cand, P->cand_cap, P->shortl, P->counters, P->K, box, dir,
                        ctx->anchors, nms_mode, P->sel, P->boxes, P->nbox, P->dirl);
@@ -708,7 +737,7 @@ int pp_postprocess_group(pp_ctx* ctx, int b0, int g, float* det, int32_t* det_co
     hipLaunchKernelGGL(post_filter_b, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n, g), dim3(256), 0, stream, tab, c, c.score_threshold,
                        P->thr_bits, P->bin_shift, P->cand_cap);
     hipLaunchKernelGGL(post_thresh_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, P->K);
-    hipLaunchKernelGGL(post_gather_b, dim3(pp_div_up(P->cand_cap, 256), n, g), dim3(256), 0, stream, tab, P->cand_cap, P->thr_bits, P->bin_shift);
+    hipLaunchKernelGGL(post_gather_b, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n, g), dim3(256), 0, stream, tab, P->cand_cap, P->thr_bits, P->bin_shift);
     hipLaunchKernelGGL(post_topk_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, c, P->cand_cap, P->K, ctx->anchors, nms_mode);
     hipLaunchKernelGGL(nms_mask_b, dim3(P->cb, P->cb, n * g), dim3(64), 0, stream, tab, n, P->K, P->cb, c.nms_iou_threshold, nms_mode);
     hipLaunchKernelGGL(nms_reduce_b, dim3(1, 1, g), dim3(512), 0, stream, tab, c, P->K, P->cb, det + (size_t)b0 * det_fs, det_fs,
