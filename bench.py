@@ -101,6 +101,63 @@ def cpu_baseline(synth, n_frames=8):
             "sample": f"{n_frames} frames of eight_20cm (20k-pt clouds, batch=1) after 1 warm-up, oracle/ CPU path, {dt:.1f} s"}
 
 
+def extras(eng, clouds, dev, NB, rows):
+    """Untimed side measurements for the report (rank 0, N=1, after the timed region):
+    * the PCIe-inclusive rate: the same pass with the clouds in pinned HOST memory, their H2D copies enqueued ahead
+      of pp_infer_batch on the same stream (SURVEY 8(d)'s timer; never `value`);
+    * single-frame latency of the stand-alone stage entry points in the reference's buckets (train.py:224-236):
+      pre = voxelise + anchor mask, net = PFN + scatter + backbone + head, post = post-processing."""
+    out = {}
+    host = [c.cpu().pin_memory() for c in clouds]
+    stage = [[torch.empty_like(c) for c in clouds[:1] * NB] for _ in range(2)]
+    for b in range(NB):
+        for k in range(2):
+            stage[k][b] = torch.empty_like(clouds[b % len(clouds)])
+    det = torch.zeros((NB, rows, 9), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((NB, 1 + 8), dtype=torch.int32, device=dev)
+    det_h = torch.zeros((NB, rows, 9), dtype=torch.float32).pin_memory()
+    cnt_h = torch.zeros((NB, 1 + 8), dtype=torch.int32).pin_memory()
+
+    def hstep(i):
+        bufs = stage[i & 1]
+        for b in range(NB):
+            bufs[b].copy_(host[b % len(host)], non_blocking=True)
+        eng.infer_batch(bufs, det, cnt)
+        det_h.copy_(det, non_blocking=True)
+        cnt_h.copy_(cnt, non_blocking=True)
+
+    for i in range(2):
+        hstep(i)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for i in range(n):
+        hstep(i)
+    torch.cuda.synchronize()
+    out["value_with_h2d"] = round(n * NB / (time.perf_counter() - t0), 3)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0, 0.0, 0.0]
+    reps = 5
+    for r in range(reps + 1):
+        pts = clouds[r % len(clouds)]
+        ev[0].record()
+        vox, coors, npts, num = eng.voxelize(pts)
+        mask = eng.anchor_mask(coors, num)
+        ev[1].record()
+        cls, box, dr = eng.head(eng.backbone(eng.scatter(eng.pfn(vox, coors, npts, num), coors, num)))
+        ev[2].record()
+        eng.postprocess(cls, box, dr, mask)
+        ev[3].record()
+        torch.cuda.synchronize()
+        if r:  # first repetition warms up
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+    out["stage_ms_single_frame"] = {"pre": round(acc[0] / reps, 4), "net": round(acc[1] / reps, 4), "post": round(acc[2] / reps, 4),
+                                    "note": "stand-alone stage entry points, one frame, dense canvas (the fused batched path shares launches across frames)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,7 +171,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16,
                     help="independent frames per pass on one stream (pp_infer_batch: frame = grid.z of the conv launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (PCIe-inclusive rate, stage latencies)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +277,8 @@ def main():
             out["roofline"]["algorithm"] = "Winograd F(2x2,3x3): executed MFMA flops = algorithmic x 4/9"
             out["roofline"]["executed"] = round(ach * 4.0 / 9.0, 3)
             out["roofline"]["executed_frac"] = round(ach * 4.0 / 9.0 / F32_MFMA_PEAK_TFLOPS, 4)
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(eng, clouds, dev, NB, rows)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, args.cpu_frames)
         print(json.dumps(out), flush=True)
