@@ -364,8 +364,8 @@ __device__ __forceinline__ bool seg_inter(const float* p1, const float* p2, int 
     }
     return false;
 }
-__device__ float rotated_iou_dev(const float* r1, const float* r2)
-{ // devRotateIoU / inter, eval/iou.py:377-399
+__device__ float rotated_inter_dev(const float* r1, const float* r2)
+{ // inter, eval/iou.py:377-391
     float p1[8], p2[8], px[16], py[16], vs[16], t[2];
     int n = 0;
     rb_corners(r1, p1);
@@ -399,6 +399,11 @@ __device__ float rotated_iou_dev(const float* r1, const float* r2)
         for (int i = 0; i < n - 2; ++i) // area, :170-177
             area += fabsf(((px[0] - px[i + 2]) * (py[i + 1] - py[i + 2]) - (py[0] - py[i + 2]) * (px[i + 1] - px[i + 2])) / 2.0f);
     }
+    return area;
+}
+__device__ __forceinline__ float rotated_iou_dev(const float* r1, const float* r2)
+{ // devRotateIoU, eval/iou.py:394-399
+    const float area = rotated_inter_dev(r1, r2);
     return area / (r1[2] * r1[3] + r2[2] * r2[3] - area);
 }
 
@@ -796,6 +801,25 @@ __global__ void __launch_bounds__(256) k_rotated_iou(const float* __restrict__ a
     iou[t] = rotated_iou_dev(r1, r2);
 }
 
+// rotate_iou_kernel_eval, eval/iou.py:563-603: out[i,j] = devRotateIoUEval(query j, box i, criterion)
+__global__ void __launch_bounds__(256) k_rotated_iou_eval(const float* __restrict__ boxes, const float* __restrict__ qboxes, float* __restrict__ out,
+                                                          int n, int k, int criterion)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * k) return;
+    const int i = (int)(t / k), j = (int)(t % k);
+    float r1[5], r2[5];
+    for (int q = 0; q < 5; ++q) { r1[q] = qboxes[j * 5 + q]; r2[q] = boxes[i * 5 + q]; }
+    const float area1 = r1[2] * r1[3], area2 = r2[2] * r2[3];
+    const float ai = rotated_inter_dev(r1, r2);
+    float v;
+    if (criterion == -1) v = ai / (area1 + area2 - ai);
+    else if (criterion == 0) v = ai / area1;
+    else if (criterion == 1) v = ai / area2;
+    else v = ai;
+    out[t] = v;
+}
+
 // sort dets by score (desc, ties by lower index) into nbox[n][6] (+ order[n]); one workgroup, n <= MAXK
 __global__ void __launch_bounds__(1024) k_nms_sort(const float* __restrict__ dets, int n, int stride, float* __restrict__ nbox,
                                                    int32_t* __restrict__ order, int32_t* __restrict__ nsel)
@@ -866,6 +890,16 @@ extern "C" int pp_rotated_iou(const float* a, const float* b, float* iou, int n,
     if (n < 0 || m < 0 || ((int64_t)n * m > 0 && (!a || !b || !iou))) return PP_E_ARG;
     if ((int64_t)n * m == 0) return 0;
     hipLaunchKernelGGL(k_rotated_iou, dim3(pp_div_up((int64_t)n * m, 256)), dim3(256), 0, (hipStream_t)stream, a, b, iou, n, m);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int pp_rotated_iou_eval(const float* boxes, const float* qboxes, float* out, int n, int k, int criterion, void* stream)
+{
+    if (n < 0 || k < 0 || criterion < -1 || criterion > 2) return PP_E_ARG;
+    if (n == 0 || k == 0) return 0;
+    if (!boxes || !qboxes || !out) return PP_E_ARG;
+    hipLaunchKernelGGL(k_rotated_iou_eval, dim3(pp_div_up((int64_t)n * k, 256)), dim3(256), 0, (hipStream_t)stream, boxes, qboxes, out, n, k, criterion);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

@@ -122,6 +122,23 @@ int pp_standup2d(const float* corners /*[n,4,2]*/, float* boxes /*[n,4]*/, int64
 int pp_nms(const float* dets, int n, int stride, float thresh, int32_t* keep, int32_t* nkeep, int rotate, void* stream);
 int pp_rotated_iou(const float* boxes_a /*[n,5]*/, const float* boxes_b /*[m,5]*/, float* iou /*[n,m]*/, int n, int m, void* stream);
 
+/* ---- evaluation ----
+ * pp_rotated_iou_eval replaces rotate_iou_gpu_eval (eval/iou.py:540-638): out[i,j] for box i and query j with
+ * criterion -1: IoU, 0: inter / area(query), 1: inter / area(box), 2: intersection area -- the reference's kernel
+ * hands the QUERY box to devRotateIoUEval first (:600-603).  Device pointers, boxes are (cx,cy,dx,dy,angle).
+ * pp_eval_statistics / pp_eval_fused_statistics replace the numba host loops compute_statistics_jit and
+ * fused_compute_statistics (eval/eval.py:62-119,182-216); HOST pointers, no GPU work.  overlaps is row-major
+ * [det rows][gt columns] with `ov_ld` doubles per row; ignored_* are the reference's -1/0/1 codes.
+ * thresholds_out must hold gt_size doubles; pr is [nthresh][4] and accumulated into (tp, fp, fn, unused). */
+int pp_rotated_iou_eval(const float* boxes /*[n,5]*/, const float* qboxes /*[k,5]*/, float* out /*[n,k]*/, int n, int k, int criterion,
+                        void* stream);
+int pp_eval_statistics(const double* overlaps, int64_t ov_ld, int det_size, int gt_size, const int64_t* ignored_gt,
+                       const int64_t* ignored_det, const float* dt_scores, double min_overlap, double thresh, int compute_fp,
+                       int64_t* tp_fp_fn /*[3]*/, double* thresholds_out, int64_t* n_thresholds);
+int pp_eval_fused_statistics(const double* overlaps, int64_t ov_ld, double* pr, const int64_t* gt_nums, const int64_t* dt_nums,
+                             int n_frames, const int64_t* ignored_gts, const int64_t* ignored_dets, const float* dt_scores,
+                             double min_overlap, const double* thresholds, int n_thresholds);
+
 /* Measurement hooks for bench.py: between begin and end every launch of the dominant kernel
  * (conv3x3 stride 1 on the level-0 map, 3 launches per frame) is bracketed by hipEvents on the
  * launch stream.  pp_profile_end synchronises the events and reports the average duration (ms),

@@ -74,3 +74,14 @@ def rotated_iou(r1, r2):
     a = np.ascontiguousarray(r1, dtype=np.float32)
     b = np.ascontiguousarray(r2, dtype=np.float32)
     return float(lib().orc_rotated_iou(_p(a, ctypes.c_float), _p(b, ctypes.c_float)))
+
+
+def rotated_iou_eval(boxes, qboxes, criterion=-1):
+    """rotate_iou_gpu_eval (eval/iou.py:606-638): f32 in/out, result cast back to the input dtype."""
+    dt = np.asarray(boxes).dtype
+    b = np.ascontiguousarray(boxes, dtype=np.float32)
+    q = np.ascontiguousarray(qboxes, dtype=np.float32)
+    out = np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+    if b.shape[0] and q.shape[0]:
+        lib().orc_rotated_iou_eval(_p(b, ctypes.c_float), b.shape[0], _p(q, ctypes.c_float), q.shape[0], int(criterion), _p(out, ctypes.c_float))
+    return out.astype(dt)

@@ -155,7 +155,7 @@ static int seg_inter(const float *p1, const float *p2, int i, int j, float *out)
     }
     return 0;
 }
-float orc_rotated_iou(const float *r1, const float *r2) /* devRotateIoU :394-399, inter :377-391 */
+float orc_rotated_inter(const float *r1, const float *r2) /* inter :377-391 */
 {
     float p1[8], p2[8], px[16], py[16], vs[16], t[2];
     int n = 0;
@@ -188,7 +188,29 @@ float orc_rotated_iou(const float *r1, const float *r2) /* devRotateIoU :394-399
         for (int i = 0; i < n - 2; ++i) /* area :170-177 */
             area += fabsf(((px[0] - px[i + 2]) * (py[i + 1] - py[i + 2]) - (py[0] - py[i + 2]) * (px[i + 1] - px[i + 2])) / 2.0f);
     }
+    return area;
+}
+float orc_rotated_iou(const float *r1, const float *r2) /* devRotateIoU :394-399 */
+{
+    float area = orc_rotated_inter(r1, r2);
     return area / (r1[2] * r1[3] + r2[2] * r2[3] - area);
+}
+/* rotate_iou_gpu_eval, eval/iou.py:540-638: out[i,j] = devRotateIoUEval(query j, box i, criterion) -- the kernel
+ * passes the QUERY box first (:600-603), so criterion 0 divides by the query's area, 1 by the box's. */
+void orc_rotated_iou_eval(const float *boxes, int n, const float *qboxes, int k, int criterion, float *out)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            const float *r1 = qboxes + 5 * (size_t)j, *r2 = boxes + 5 * (size_t)i;
+            float area1 = r1[2] * r1[3], area2 = r2[2] * r2[3];
+            float ai = orc_rotated_inter(r1, r2);
+            float v;
+            if (criterion == -1) v = ai / (area1 + area2 - ai);
+            else if (criterion == 0) v = ai / area1;
+            else if (criterion == 1) v = ai / area2;
+            else v = ai;
+            out[(size_t)i * k + j] = v;
+        }
 }
 
 /* eval/iou.py:438-473 rotate_nms_gpu. dets f32[n,6] (cx,cy,dx,dy,angle,score). */

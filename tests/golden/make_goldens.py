@@ -2,6 +2,7 @@
 """Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
 
     python tests/golden/make_goldens.py            (needs /root/reference; ~2-4 min)
+    python tests/golden/make_goldens.py --only eval   (just eval_ap.npz, seconds)
 
 The reference (1005088h/3d_object_detection, pure Python) never travels: only
 the inputs/outputs captured here are committed.  How each piece is run:
@@ -107,6 +108,113 @@ def ref_nms_from_device_fn(iou_fn, postprocess, dets, thresh, ncol):
     keep = np.zeros([n], dtype=np.int32)
     num = postprocess(keep, mask, n)
     return [int(v) for v in order[keep[:num]]], order
+
+
+def synth_eval_annos(seed=0, frames=53):  # eval.py:173-180 splits into 50 parts and fails on fewer frames
+    """Small seeded evaluation set: per frame a few ground-truth boxes of the three classes (some without points,
+    some out of range, one unknown label) and detections = jittered ground truth + false positives.  float32
+    arrays like the reference's pipeline produces (inference.py:124-138)."""
+    rng = np.random.default_rng(seed)
+    sizes = {"vehicle": (4.5, 1.9, 1.6), "pedestrian": (0.8, 0.7, 1.75), "cyclist": (1.8, 0.7, 1.7)}
+    names = list(sizes)
+    gts, dts = [], []
+    for f in range(frames):
+        ng = int(rng.integers(0, 9)) if f != 3 else 0  # one frame without ground truth
+        g = {"name": [], "location": [], "dimensions": [], "rotation_y": [], "num_points": []}
+        for _ in range(ng):
+            c = names[int(rng.integers(0, 3))] if rng.random() > 0.08 else "cone"
+            s = sizes.get(c, (0.5, 0.5, 0.8))
+            r = rng.uniform(4, 95)
+            a = rng.uniform(-np.pi, np.pi)
+            g["name"].append(c)
+            g["location"].append([r * np.cos(a), r * np.sin(a), rng.uniform(-1.2, -0.4)])
+            g["dimensions"].append([s[0] * rng.uniform(0.85, 1.15), s[1] * rng.uniform(0.85, 1.15), s[2] * rng.uniform(0.9, 1.1)])
+            g["rotation_y"].append(rng.uniform(-np.pi, np.pi))
+            g["num_points"].append(int(rng.choice([0, 3, 5, 6, 40, 400])))
+        gt = {"name": np.array(g["name"], dtype="<U10"), "location": np.array(g["location"], np.float32).reshape(-1, 3),
+              "dimensions": np.array(g["dimensions"], np.float32).reshape(-1, 3), "rotation_y": np.array(g["rotation_y"], np.float32),
+              "num_points": np.array(g["num_points"], np.int32)}
+        d = {"name": [], "location": [], "dimensions": [], "rotation_y": [], "score": []}
+        for i in range(ng):
+            if g["name"][i] == "cone" or rng.random() < 0.2:
+                continue
+            jit = rng.choice([0.05, 0.3, 0.9])
+            d["name"].append(g["name"][i] if rng.random() > 0.1 else names[int(rng.integers(0, 3))])
+            d["location"].append(list(np.array(g["location"][i]) + rng.normal(0, jit, 3) * [1, 1, 0.2]))
+            d["dimensions"].append(list(np.array(g["dimensions"][i]) * rng.uniform(0.9, 1.1, 3)))
+            d["rotation_y"].append(g["rotation_y"][i] + rng.normal(0, 0.1 * jit))
+            d["score"].append(rng.uniform(0.3, 0.99))
+            if rng.random() < 0.25:  # duplicate detection of the same object
+                d["name"].append(d["name"][-1]); d["location"].append(list(np.array(d["location"][-1]) + 0.1))
+                d["dimensions"].append(d["dimensions"][-1]); d["rotation_y"].append(d["rotation_y"][-1]); d["score"].append(rng.uniform(0.1, 0.6))
+        for _ in range(int(rng.integers(0, 5))):  # false positives
+            c = names[int(rng.integers(0, 3))]
+            r = rng.uniform(4, 95); a = rng.uniform(-np.pi, np.pi)
+            d["name"].append(c); d["location"].append([r * np.cos(a), r * np.sin(a), -0.8]); d["dimensions"].append(list(sizes[c]))
+            d["rotation_y"].append(rng.uniform(-np.pi, np.pi)); d["score"].append(rng.uniform(0.05, 0.7))
+        dt = {"name": np.array(d["name"], dtype="<U10"), "location": np.array(d["location"], np.float32).reshape(-1, 3),
+              "dimensions": np.array(d["dimensions"], np.float32).reshape(-1, 3), "rotation_y": np.array(d["rotation_y"], np.float32),
+              "score": np.array(d["score"], np.float32)}
+        gts.append(gt)
+        dts.append(dt)
+    return gts, dts
+
+
+def pack_annos(annos, keys):
+    out = {"count": np.array([len(a["name"]) for a in annos], np.int32)}
+    for k in keys:
+        parts = [a[k] for a in annos]
+        out[k] = np.concatenate(parts, 0) if parts else np.zeros((0,))
+    return out
+
+
+def make_eval_goldens():
+    """eval/eval.py:233-483 (KITTI-style AP) on a small seeded set.  The only CUDA piece,
+    rotate_iou_gpu_eval (eval/iou.py:562-638), is emulated by calling the reference's own device function
+    devRotateIoUEval(query_box, box, criterion) for every (box, query) pair -- the argument order and the output
+    index the kernel uses (:600-603); everything else of eval.py runs as the Python it is written in."""
+    install_shims()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    from eval import iou as ref_iou
+    from eval import eval as ref_eval
+
+    def rotate_iou_gpu_eval_emulated(boxes, query_boxes, criterion=-1, device_id=0):
+        dt = boxes.dtype
+        b = boxes.astype(np.float32)
+        q = query_boxes.astype(np.float32)
+        out = np.zeros((b.shape[0], q.shape[0]), np.float32)
+        for i in range(b.shape[0]):
+            for j in range(q.shape[0]):
+                out[i, j] = ref_iou.devRotateIoUEval(q[j], b[i], criterion)
+        return out.astype(dt)
+
+    ref_eval.rotate_iou_gpu_eval = rotate_iou_gpu_eval_emulated
+    gts, dts = synth_eval_annos(seed=0)
+    classes = ["vehicle", "pedestrian", "cyclist"]
+    res = {}
+    for rt in (80.0, 40.0):
+        results, eval_str = ref_eval.get_official_eval_result([dict(g) for g in gts], [dict(d) for d in dts], classes, rt)
+        res[f"map_bev_{int(rt)}"] = np.asarray(results[0], np.float64)
+        res[f"map_3d_{int(rt)}"] = np.asarray(results[1], np.float64)
+        res[f"eval_str_{int(rt)}"] = np.array(eval_str)
+        print(eval_str)
+    # intermediate pins: criterion variants of the rotated overlap, BEV and 3-D overlaps of frame 0 (dt rows, gt cols)
+    rng = np.random.default_rng(5)
+    rb = np.concatenate([rng.uniform(-5, 5, (24, 2)), rng.uniform(0.5, 5, (24, 2)), rng.uniform(-3.2, 3.2, (24, 1))], 1).astype(np.float32)
+    rb[3] = rb[2]            # identical boxes
+    rb[5, :2] = rb[4, :2]    # concentric
+    crit = {str(c): rotate_iou_gpu_eval_emulated(rb[:10], rb[8:], c) for c in (-1, 0, 1, 2)}
+    ov_bev, _, _, _ = ref_eval.calculate_iou_partly_lidar(dts, gts, "bev", 50)
+    ov_3d, _, _, _ = ref_eval.calculate_iou_partly_lidar(dts, gts, "3d", 50)
+    ret = ref_eval.eval_class_AP(gts, dts, classes, "3d", {"vehicle": [0.7, 0.5], "pedestrian": [0.5, 0.25], "cyclist": [0.5, 0.25]},
+                                 "lidar", 5, range_thresh=80.0)
+    g = pack_annos(gts, ["name", "location", "dimensions", "rotation_y", "num_points"])
+    d = pack_annos(dts, ["name", "location", "dimensions", "rotation_y", "score"])
+    save("eval_ap", rb=rb, crit_m1=crit["-1"], crit_0=crit["0"], crit_1=crit["1"], crit_2=crit["2"],
+         **{"gt_" + k: v for k, v in g.items()}, **{"dt_" + k: v for k, v in d.items()},
+         ov_bev_0=ov_bev[0], ov_3d_0=ov_3d[0], ov_bev_5=ov_bev[5], ov_3d_5=ov_3d[5],
+         precision_3d_80=ret["precision"], recall_3d_80=ret["recall"], **res)
 
 
 def main():
@@ -308,4 +416,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "eval":
+        make_eval_goldens()
+    else:
+        main()
+        make_eval_goldens()
