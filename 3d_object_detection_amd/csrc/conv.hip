@@ -55,6 +55,9 @@ __device__ __forceinline__ BlockId xcd_block_id()
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// dword-aligned vector stores (global memory takes multi-dword accesses at dword alignment)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr int NREP = 8; // replicated statistics accumulators (spreads atomic contention)
 
@@ -513,101 +516,61 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     float* scl = wl + 2 * C::LDS_W;
     float* shl = scl + 320;
     float* red = shl + 320;
-    // frame of this workgroup (batched launch)
-    const BlockId bid = xcd_block_id();
-    const size_t fz = bid.z;
-    const float* __restrict__ gin = p.in + fz * p.in_fs;
-    float* __restrict__ gout = p.out + fz * p.out_fs;
-    const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
-    const double* __restrict__ gpre = p.pre_acc ? p.pre_acc + fz * p.pre_fs : nullptr;
-    double* __restrict__ gstat = p.stat_acc ? p.stat_acc + fz * p.stat_fs : nullptr;
-    float* __restrict__ gbox = p.out_box ? p.out_box + fz * p.box_fs : nullptr;
-    float* __restrict__ gdir = p.out_dir ? p.out_dir + fz * p.dir_fs : nullptr;
-    (void)gbox; (void)gdir;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m = lane & 15, kq = lane >> 4;
 
-    const int nbx = (p.Wout + C::PW - 1) / C::PW;
-    const int bx = bid.x % nbx, by = bid.x / nbx;
-    const int co0 = bid.y * C::BM;
-    const int ox0 = bx * C::PW, oy0 = by * C::PH;
-    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
-
-    if (p.pre == PRE_STATS) {
-        for (int c = tid; c < p.Cin; c += C::THREADS) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) {
-                s += gpre[((size_t)r * p.Cin + c) * 2];
-                q += gpre[((size_t)r * p.Cin + c) * 2 + 1];
-            }
-            double mean = s * p.pre_inv_n;
-            double var = q * p.pre_inv_n - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            double rstd = 1.0 / sqrt(var + (double)p.eps);
-            scl[c] = (float)rstd;
-            shl[c] = (float)(-mean * rstd);
-        }
-    } else if (p.pre == PRE_AFFINE) {
-        for (int c = tid; c < p.Cin; c += C::THREADS) {
-            scl[c] = p.pre_scale[fz * p.aff_fs + c];
-            shl[c] = p.pre_shift[fz * p.aff_fs + c];
-        }
-    }
-
-    // byte offsets inside a channel plane (buffer loads: SGPR base + 32-bit VGPR offset, no 64-bit address math)
+    // PERSISTENT: two workgroups per CU walk the (cout block, tile, frame) list.  Workgroups are dealt round-robin
+    // over the 8 XCDs, so XCD k takes the k-th contiguous eighth of the list (cout blocks of a tile and
+    // neighbouring tiles meet in one L2) and its workgroups stride through that eighth.  Per tile this saves the
+    // launch slot + scale/shift prologue of a fresh workgroup, and the next tile's first loads are in flight while
+    // the stores of this tile's epilogue drain.
+    const int nbx = (p.Wout + C::PW - 1) / C::PW, nby = (p.Hout + C::PH - 1) / C::PH;
+    const int ntile = nbx * nby, ncb = (p.Cout + C::BM - 1) / C::BM;
+    const int total = ntile * ncb * p.nb;
+    const int per = (total + 7) >> 3;
+    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int lin_end = min(total, (xk + 1) * per);
+    // ---- load-side state: the tile whose global loads are being issued.  It runs one tile AHEAD of the compute
+    //      side at a tile boundary: the next tile's first chunk is requested before this tile's epilogue, so its
+    //      latency hides under the output transform and stores.
     int goff[C::PR], loff[C::PR];
     unsigned vmask = 0u;
+    bool all_in = false;
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned plane_b = (unsigned)(p.Hin * p.Win) * 4u;
+    unsigned wbase_b = 0u;
+    float xv[C::PR][KC];
+    f32x4 wv[C::WR];
 #pragma unroll
     for (int r = 0; r < C::PR; ++r) {
         // threads past the patch's last position duplicate it (same load, same value to the same LDS word):
         // every staging instruction is unconditional, the MFMA stream stays one basic block
         const int pos = min(tid + r * C::THREADS, C::NPOS - 1);
         const int iy = pos / C::IW, ix = pos - iy * C::IW;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool inb = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-        goff[r] = inb ? (gy * p.Win + gx) * 4 : 0;
-        vmask |= (inb ? 1u : 0u) << r;
         loff[r] = iy * C::IWP + (ix & 1) * C::HALF + (ix >> 1);
     }
-    // interior patches (the vast majority) need no zero-padding select at all: workgroup-uniform fast path
-    const bool all_in = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::IH <= p.Hin) && (ix0 + C::IW <= p.Win);
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gin), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, 0x7FFFFFFF, 0x00020000);
-    const unsigned plane_b = (unsigned)(p.Hin * p.Win) * 4u;
-    const unsigned wbase_b = (unsigned)((size_t)bid.y * (p.Cin / KC) * C::W4 * 16);
-
-    // this lane's tile: block-local tile coords -> top-left output pixel and raw-patch base
-    const int btx = wn % BTX, bty = wn / BTX;
-    const int ttx = btx * TWT + (m % TWT), tty = bty * C::THT + (m / TWT);
-    const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
-    const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
-    const int aoff = kq * C::BMP + wm * 32 + m * 2; // float2 {M-tile 0, M-tile 1}
-
-    f32x4 acc[MT][16];
+    auto set_load_tile = [&](int l) {
+        const int cb_ = l % ncb, t_ = (l / ncb) % ntile, f_ = l / (ncb * ntile);
+        const int iy0_ = (t_ / nbx) * C::PH - 1, ix0_ = (t_ % nbx) * C::PW - 1;
+        vmask = 0u;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) acc[i][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nchunk = p.Cin / KC;
-
-    float xv[C::PR][KC];
-    f32x4 wv[C::WR];
-
-    // ---- software-pipelined chunk loop ------------------------------------------------------------
-    // One register set holds the NEXT chunk's raw loads.  Per chunk (after its opening barrier):
-    //   * LDS reads of this chunk's first channel quad are issued first, and the staged registers are
-    //     normalised (VALU that needs no LDS) while those reads are in flight
-    //   * the normalised registers are written to the OTHER LDS buffer one piece per MFMA step, then the
-    //     loads of chunk ch+2 are re-issued -- they have until the next barrier (> half a chunk) to land
-    //   * the input transform is cut in two: the column pass of quad q+1 is spread over the steps of
-    //     quad q, the row pass is one add per step right before its MFMA pair
-    // so a wave keeps issuing MFMAs by itself instead of relying on another wave being out of phase.
+        for (int r = 0; r < C::PR; ++r) {
+            const int pos = min(tid + r * C::THREADS, C::NPOS - 1);
+            const int iy = pos / C::IW, ix = pos - iy * C::IW;
+            const int gy = iy0_ + iy, gx = ix0_ + ix;
+            const bool inb = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+            goff[r] = inb ? (gy * p.Win + gx) * 4 : 0; // byte offset inside a channel plane (SGPR base + 32-bit VGPR offset)
+            vmask |= (inb ? 1u : 0u) << r;
+        }
+        // interior patches (the vast majority) need no zero-padding select at all: workgroup-uniform fast path
+        all_in = (iy0_ >= 0) && (ix0_ >= 0) && (iy0_ + C::IH <= p.Hin) && (ix0_ + C::IW <= p.Win);
+        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)f_ * p.in_fs), 0, 0x7FFFFFFF, 0x00020000);
+        wbase_b = (unsigned)((size_t)cb_ * (p.Cin / KC) * C::W4 * 16);
+    };
 #define WN_LOAD_X(CH, R)                                                                         \
     {                                                                                            \
         const unsigned cb_ = (unsigned)((CH) * KC) * plane_b;                                    \
@@ -627,6 +590,63 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r) WN_LOAD_X(CH, r)                       \
         WN_LOAD_W(CH)                                                                            \
     }
+    int cur_frame = -1;
+    {
+        const int lin0 = xk * per + xj;
+        if (lin0 < lin_end) {
+            set_load_tile(lin0);
+            if (!(p.dbg & 1)) WN_LOAD_CHUNK(0)
+        }
+    }
+    for (int lin = xk * per + xj; lin < lin_end; lin += nloc) {
+    BlockId bid;
+    bid.y = lin % ncb;
+    bid.x = (lin / ncb) % ntile;
+    bid.z = lin / (ncb * ntile);
+    const size_t fz = bid.z;
+    float* __restrict__ gout = p.out + fz * p.out_fs;
+    const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
+    double* __restrict__ gstat = p.stat_acc ? p.stat_acc + fz * p.stat_fs : nullptr;
+
+    const int bx = bid.x % nbx, by = bid.x / nbx;
+    const int co0 = bid.y * C::BM;
+    const int ox0 = bx * C::PW, oy0 = by * C::PH;
+
+    // (scale, shift) of the producer's normalisation: per frame, written by norm_finalize (PRE_AFFINE) -- reloaded
+    // only when this workgroup moves to another frame.  Every wave is past the previous tile's last chunk barrier
+    // here, so nobody still reads the arrays; the prologue's first barrier publishes them.
+    if (p.pre != PRE_RAW && bid.z != cur_frame) {
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            scl[c] = p.pre_scale[fz * p.aff_fs + c];
+            shl[c] = p.pre_shift[fz * p.aff_fs + c];
+        }
+        cur_frame = bid.z;
+    }
+
+    // this lane's tile: block-local tile coords -> top-left output pixel and raw-patch base
+    const int btx = wn % BTX, bty = wn / BTX;
+    const int ttx = btx * TWT + (m % TWT), tty = bty * C::THT + (m / TWT);
+    const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
+    const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
+    const int aoff = kq * C::BMP + wm * 32 + m * 2; // float2 {M-tile 0, M-tile 1}
+
+    f32x4 acc[MT][16];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[i][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.Cin / KC;
+
+    // ---- software-pipelined chunk loop ------------------------------------------------------------
+    // One register set holds the NEXT chunk's raw loads.  Per chunk (after its opening barrier):
+    //   * LDS reads of this chunk's first channel quad are issued first, and the staged registers are
+    //     normalised (VALU that needs no LDS) while those reads are in flight
+    //   * the normalised registers are written to the OTHER LDS buffer one piece per MFMA step, then the
+    //     loads of chunk ch+2 are re-issued -- they have until the next barrier (> half a chunk) to land
+    //   * the input transform is cut in two: the column pass of quad q+1 is spread over the steps of
+    //     quad q, the row pass is one add per step right before its MFMA pair
+    // so a wave keeps issuing MFMAs by itself instead of relying on another wave being out of phase.
 // normalise + ReLU + zero padding of the staged registers (chunk CH), in place
 #define WN_NORM_CHUNK(CH)                                                                        \
     {                                                                                            \
@@ -688,7 +708,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     // A operands run AD steps ahead of their MFMAs (a step is only 2 MFMAs = 64 cycles; LDS latency is 2-3x that)
     constexpr int AD = 6;
 
-    if (!(p.dbg & 1)) WN_LOAD_CHUNK(0)
+    // chunk 0 of this tile was requested before the previous tile's epilogue (or ahead of the loop)
     __syncthreads(); // scl / shl visible
     WN_NORM_CHUNK(0)
     pp_steps<0, NPIECE>([&](auto E) { WN_WRITE_PIECE(decltype(E)::value, 0) });
@@ -762,17 +782,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #undef WN_LOAD_A
         __syncthreads();
     }
-#undef WN_LOAD_X
-#undef WN_LOAD_W
-#undef WN_LOAD_CHUNK
 #undef WN_NORM_CHUNK
 #undef WN_WRITE_PIECE
 #undef WN_READ_RAW
 #undef WN_COLPASS
 #undef WN_ROWPASS
 
+    if (lin + nloc < lin_end) { // next tile's first chunk: in flight during the epilogue below
+        set_load_tile(lin + nloc);
+        if (!(p.dbg & 1)) WN_LOAD_CHUNK(0)
+    }
     // ---- epilogue: Y = A^T M A per lane, residual, store (float2 rows), statistics ----
-    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) gout[0] = 1.f; return; }
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) gout[0] = 1.f; continue; }
     const size_t out_plane = (size_t)p.Hout * p.Wout;
     float ssum[MT][4], ssq[MT][4];
     const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
@@ -852,6 +873,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             atomicAdd(dst + 1, q);
         }
     }
+    } // tile loop
+#undef WN_LOAD_X
+#undef WN_LOAD_W
+#undef WN_LOAD_CHUNK
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1242,9 +1267,51 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
     };
 
     const int aoff = kq * BMP + m;
+    static_assert(NT == 4, "gemm1x1 is written for 4 interleaved N-tiles");
+    const int nsteps = K / 4;
+    const unsigned bstep = 16u * (unsigned)plane; // bytes between channel quads
+    // ---- load-side state of the item whose B quads are being requested.  At an item boundary it runs one item
+    //      AHEAD: the next item's first PD-1 quads are requested BEFORE this item's epilogue, so they are older than
+    //      its stores in the (in-order) vmcnt queue and their latency hides under the epilogue.
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0x7FFFFFFF, 0x00020000);
+    unsigned bvoff = 0u;
+    f32x4 bq[PD];
+    auto set_load_item = [&](int it) {
+        const int f_ = __builtin_amdgcn_readfirstlane(it / items_per_frame); // the division runs on the VALU: pin the
+        const int px_ = __builtin_amdgcn_readfirstlane((it - f_ * items_per_frame) * (NT * 16)) + 4 * m; // results in SGPRs
+        // descriptor base pinned to SGPRs (a VGPR-resident descriptor costs a waterfall loop per load)
+        const uint64_t bp_ = (uint64_t)(p.in + (size_t)f_ * p.in_fs);
+        const uint64_t bps_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp_);
+        rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bps_), 0, 0x7FFFFFFF, 0x00020000);
+        bvoff = ((unsigned)kq * (unsigned)plane + (unsigned)(px_ < HW ? px_ : 0)) * 4u;
+    };
+#define G1_LOADB(S, SLOT) bq[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff, (unsigned)(S) * bstep, 0));
+#define G1_PREP(S, SLOT, PAR)                                                                    \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[PAR][i] = wl[(S) * 4 * BMP + aoff + i * 16]; \
+        if (p.pre != PRE_RAW) {                                                                  \
+            const float sc = scl[(S) * 4 + kq], sh = shl[(S) * 4 + kq];                          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = fmaxf(fmaf(bq[SLOT][j], sc, sh), 0.f); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = bq[SLOT][j];              \
+        }                                                                                        \
+    }
+#define G1_MFMAS(PAR)                                                                            \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PAR][i], b[PAR][j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+    if (gw < total) {
+        set_load_item(gw);
+#pragma unroll
+        for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
+    }
     for (int item = gw; item < total; item += gstride) {
-        const int fr = __builtin_amdgcn_readfirstlane(item / items_per_frame); // the division runs on the VALU: pin the
-        const int pix0 = __builtin_amdgcn_readfirstlane((item - fr * items_per_frame) * (NT * 16)); // wave-uniform results in SGPRs
+        const int fr = __builtin_amdgcn_readfirstlane(item / items_per_frame);
+        const int pix0 = __builtin_amdgcn_readfirstlane((item - fr * items_per_frame) * (NT * 16));
         if (fr != stat_frame) { flush_stats(stat_frame); stat_frame = fr; }
         if (p.pre != PRE_RAW && fr != pre_frame) {
             for (int c = lane; c < K; c += 64) {
@@ -1267,10 +1334,8 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             pre_frame = fr;
         }
         // N-tile j of this item = pixels {pix0 + 4m + j}: one dwordx4 per lane and step feeds all four tiles
-        static_assert(NT == 4, "gemm1x1 is written for 4 interleaved N-tiles");
         const int pxb = pix0 + 4 * m;       // first of this lane's 4 pixels (HW % 4 == 0: all four valid or none)
         const bool pok = pxb < HW;
-        const int pof = pok ? pxb : 0;
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -1282,36 +1347,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         // offset in an SGPR -- no address VALU), the A fragments and the normalised B values of step st+1 are
         // prepared in the shadow of this step's MT*NT MFMAs, then the MFMAs issue.  The last ring is peeled so
         // that no step carries a run-time condition.
-        f32x4 bq[PD];
-        const int nsteps = K / 4;
-        // descriptor base pinned to SGPRs (a VGPR-resident descriptor costs a waterfall loop per load)
-        const uint64_t bp_ = (uint64_t)(p.in + (size_t)fr * p.in_fs);
-        const uint64_t bps_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp_);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bps_), 0, 0x7FFFFFFF, 0x00020000);
-        const unsigned bvoff = ((unsigned)kq * (unsigned)plane + (unsigned)pof) * 4u;
-        const unsigned bstep = 16u * (unsigned)plane; // bytes between channel quads
-#define G1_LOADB(S, SLOT) bq[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff, (unsigned)(S) * bstep, 0));
-#define G1_PREP(S, SLOT, PAR)                                                                    \
-    {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) a[PAR][i] = wl[(S) * 4 * BMP + aoff + i * 16]; \
-        if (p.pre != PRE_RAW) {                                                                  \
-            const float sc = scl[(S) * 4 + kq], sh = shl[(S) * 4 + kq];                          \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = fmaxf(fmaf(bq[SLOT][j], sc, sh), 0.f); \
-        } else {                                                                                 \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) b[PAR][j] = bq[SLOT][j];              \
-        }                                                                                        \
-    }
-#define G1_MFMAS(PAR)                                                                            \
-    {                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PAR][i], b[PAR][j], acc[i][j], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-    }
         float a[2][MT], b[2][NT];
-#pragma unroll
-        for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
         G1_PREP(0, 0, 0)
         int sb = 0;
         for (; sb < nsteps - PD; sb += PD) {
@@ -1329,9 +1365,12 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             if (u + 1 < PD) G1_PREP(sb + u + 1, (u + 1) % PD, (u + 1) & 1)
             G1_MFMAS(u & 1)
         }
-#undef G1_MFMAS
-#undef G1_PREP
-#undef G1_LOADB
+
+        if (item + gstride < total) { // next item's first quads, ahead of this item's stores
+            set_load_item(item + gstride);
+#pragma unroll
+            for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
+        }
 
         // ---- epilogue of this item (lane m owns pixels pxb .. pxb+3, one per N-tile) ----
         float* gout = p.out + (size_t)fr * p.out_fs;
@@ -1382,22 +1421,32 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                         for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
                     }
                 } else {
+                    // head rows in head_tile_row order: this lane's 4 rows are one output run (see the host helper)
+                    const int g = row0 >> 2;
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + row0);
+                    if (g < 9) { // box(a = g), k = 0..3
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + r;
-                        if (row >= p.n_rows) continue;
-                        const float bias = p.bias[row];
-                        if (row < p.n_cls) {
-                            const f32x4 x = (f32x4){acc[i][0][r] + bias, acc[i][1][r] + bias, acc[i][2][r] + bias, acc[i][3][r] + bias};
-                            *reinterpret_cast<f32x4*>(gout + (size_t)row * plane + pxb) = x;
-                        } else if (row < p.n_cls + p.n_box) {
-                            const int q = row - p.n_cls, a_ = q / 7, k = q - a_ * 7;
+                        for (int j = 0; j < NT; ++j) {
+                            f32x4u* o = reinterpret_cast<f32x4u*>(gbox + ((size_t)g * plane + pxb + j) * 7);
+                            *o = (f32x4u){acc[i][j][0] + bs[0], acc[i][j][1] + bs[1], acc[i][j][2] + bs[2], acc[i][j][3] + bs[3]};
+                        }
+                    } else if (g < 18) { // box(a = g - 9), k = 4..6 ; cls(a) over the lane's 4 pixels
+                        const int a_ = g - 9;
 #pragma unroll
-                            for (int j = 0; j < NT; ++j) gbox[((size_t)a_ * plane + pxb + j) * 7 + k] = acc[i][j][r] + bias;
-                        } else {
-                            const int q = row - p.n_cls - p.n_box, a_ = q >> 1, k = q & 1;
+                        for (int j = 0; j < NT; ++j) {
+                            float* o = gbox + ((size_t)a_ * plane + pxb + j) * 7 + 4;
+                            *reinterpret_cast<f32x2u*>(o) = (f32x2u){acc[i][j][0] + bs[0], acc[i][j][1] + bs[1]};
+                            o[2] = acc[i][j][2] + bs[2];
+                        }
+                        *reinterpret_cast<f32x4*>(gout + (size_t)a_ * plane + pxb) =
+                            (f32x4){acc[i][0][3] + bs[3], acc[i][1][3] + bs[3], acc[i][2][3] + bs[3], acc[i][3][3] + bs[3]};
+                    } else if (g < 23) { // dir(a0 = 2d), dir(a0 + 1)
+                        const int a0 = 2 * (g - 18);
 #pragma unroll
-                            for (int j = 0; j < NT; ++j) gdir[((size_t)a_ * plane + pxb + j) * 2 + k] = acc[i][j][r] + bias;
+                        for (int j = 0; j < NT; ++j) {
+                            *reinterpret_cast<float2*>(gdir + ((size_t)a0 * plane + pxb + j) * 2) = make_float2(acc[i][j][0] + bs[0], acc[i][j][1] + bs[1]);
+                            if (a0 + 1 < 9)
+                                *reinterpret_cast<float2*>(gdir + ((size_t)(a0 + 1) * plane + pxb + j) * 2) = make_float2(acc[i][j][2] + bs[2], acc[i][j][3] + bs[3]);
                         }
                     }
                 }
@@ -1405,6 +1454,9 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         }
     }
     flush_stats(stat_frame);
+#undef G1_MFMAS
+#undef G1_PREP
+#undef G1_LOADB
 }
 
 // y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
@@ -1569,6 +1621,7 @@ struct pp_net {
     float* bn_scale = nullptr; // BatchNorm variant: all folded (scale, shift) arrays
     float* bn_shift = nullptr;
     float* head_bias = nullptr;
+    float* head_bias_perm = nullptr; // head bias in gemm1x1's row order (head_tile_row)
     float* ones = nullptr;
     float* zeros = nullptr;
     int num_cu = 256;
@@ -1668,6 +1721,27 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
     return bv;
 }
 
+// Row order of the head inside gemm1x1.  A lane of the 16x16 MFMA tile owns 4 CONSECUTIVE tile rows (kq*4 + r), so
+// the 90 head rows are dealt to the 24 four-row groups such that a group's values are adjacent in the output:
+//   groups 0..8   box (a = g)      k = 0..3                      -> one 16-byte store per pixel
+//   groups 9..17  box (a = g - 9)  k = 4..6, then cls(a)         -> one 12-byte store per pixel + cls as a pixel quad
+//   groups 18..22 dir (a = 2d, 2d+1), both logits each           -> two 8-byte stores per pixel
+//   group 23      padding
+// (natural order: cls 0..8, box 9 + 7a + k, dir 72 + 2a + k, head rows 90..95 are zero).  With the natural order
+// the 81 box/dir rows cost 4 scalar stores each per lane -- 333 scattered store instructions per 64 pixels, whose
+// completion the next item's first loads had to wait for (vmcnt is in order): 38 % of the head's wave time.
+static inline int head_tile_row(int t)
+{
+    const int g = t >> 2, r = t & 3;
+    if (g < 9) return 9 + 7 * g + r;
+    if (g < 18) return r < 3 ? 9 + 7 * (g - 9) + 4 + r : (g - 9);
+    if (g < 23) {
+        const int a = 2 * (g - 18) + (r >> 1);
+        return a < 9 ? 72 + 2 * a + (r & 1) : -1;
+    }
+    return -1;
+}
+
 int pack_layer(pp_ctx* ctx, Layer& L)
 {
     const Variant& v = L.var;
@@ -1720,6 +1794,14 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
         rowsW.swap(u);
         taps_eff = 16;
+    }
+    if (v.wino == 3 && L.kind == 2) { // head under gemm1x1: rows in head_tile_row order
+        std::vector<float> perm((size_t)96 * L.cin, 0.f);
+        for (int t = 0; t < 96; ++t) {
+            const int src = head_tile_row(t);
+            if (src >= 0) memcpy(&perm[(size_t)t * L.cin], &rowsW[(size_t)src * L.cin], sizeof(float) * L.cin);
+        }
+        rowsW.swap(perm);
     }
     if (v.wino == 3) { // [row block][K][BMP]
         const int nb_ = pp_div_up(rows, v.bm);
@@ -1805,7 +1887,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.pre = pre.mode; p.pre_acc = pre.acc; p.pre_scale = pre.scale; p.pre_shift = pre.shift;
     p.pre_inv_n = pre.inv_n; p.eps = 1e-3f;
     p.stat_acc = stat_acc; p.stat_C = stat_C;
-    p.bias = net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
+    p.bias = (L.kind == 2 && L.var.wino == 3) ? net->head_bias_perm : net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
     p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
     { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
     {   // frame strides of a batched launch (every per-frame tensor is stored [B][...])
@@ -1834,6 +1916,13 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         const int ncb = pp_div_up(L.rows, v.bm);
         int g = (net->num_cu / ncb) * ncb;
         if (g < ncb) g = ncb;
+        grid = dim3(g, 1, 1);
+    }
+    if (v.wino == 1) { // persistent Winograd: two workgroups per CU (LDS and registers allow exactly two), a multiple of the 8 XCDs
+        const int total = (int)grid.x * (int)grid.y * B;
+        int g = 2 * net->num_cu;
+        if (g > total) g = total;
+        g = (g + 7) & ~7;
         grid = dim3(g, 1, 1);
     }
     const bool tag = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
@@ -2022,6 +2111,7 @@ int pp_net_create(pp_ctx* ctx)
     PP_HIP(hipMalloc((void**)&net->bn_scale, (size_t)24 * 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->bn_shift, (size_t)24 * 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->head_bias, 96 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->head_bias_perm, 96 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->ones, 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->zeros, 320 * sizeof(float)));
     std::vector<float> one(320, 1.f);
@@ -2065,7 +2155,7 @@ void pp_net_destroy(pp_ctx* ctx)
             if (net->buf[l][b]) (void)hipFree(net->buf[l][b]);
     for (Layer& L : net->layers)
         if (L.w) (void)hipFree(L.w);
-    void* ptrs[] = {net->up, net->stats, net->aff, net->bn_scale, net->bn_shift, net->head_bias, net->ones, net->zeros};
+    void* ptrs[] = {net->up, net->stats, net->aff, net->bn_scale, net->bn_shift, net->head_bias, net->head_bias_perm, net->ones, net->zeros};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     delete net;
@@ -2114,6 +2204,11 @@ int pp_net_commit(pp_ctx* ctx)
         r0 += cnt[h];
     }
     PP_HIP(hipMemcpy(net->head_bias, hb, sizeof(hb), hipMemcpyHostToDevice));
+    {
+        float hp[96];
+        for (int t = 0; t < 96; ++t) hp[t] = head_tile_row(t) >= 0 ? hb[head_tile_row(t)] : 0.f;
+        PP_HIP(hipMemcpy(net->head_bias_perm, hp, sizeof(hp), hipMemcpyHostToDevice));
+    }
     {
         const char* at = getenv("PP_AUTOTUNE");
         const char* vb = getenv("PP_VERBOSE");
