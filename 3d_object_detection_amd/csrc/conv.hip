@@ -464,6 +464,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 //   LDS pass, no extra barrier
 // * the OUTPUT transform is per lane too (the 16 positions of a tile are 16 accumulators of one lane)
 // ------------------------------------------------------------------------------------------
+#ifndef PP_WINO_PRIO
+#define PP_WINO_PRIO 0 // s_setprio level around each MFMA pair of the Winograd loop (0: off)
+#endif
 #ifndef PP_WINO_DIAG
 #define PP_WINO_DIAG 0 // timing-only ablations of the Winograd loop (wrong results): 1 no transform, 2 no raw reads, 4 no A reads, 8 no MFMA
 #endif
@@ -505,7 +508,10 @@ struct WinoCfg {
     static_assert(WN % BTX == 0, "tiles must form a rectangle");
 };
 
-template <int TWT, int WM, int WN, int BTX, int KC>
+// ROOFLINE: 1 instantiates a second, identical copy of the kernel for the roofline layer (3x3 s1 64->64 on the level-0
+// map) only, so that a kernel trace / --stats summary has that layer's launches under their own symbol instead of
+// averaged with the other layers the tuner gives the same tiling.
+template <int TWT, int WM, int WN, int BTX, int KC, int ROOFLINE = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfma(const ConvP p)
 {
     using C = WinoCfg<TWT, WM, WN, BTX, KC>;
@@ -590,6 +596,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         _Pragma("unroll") for (int r = 0; r < C::PR; ++r) WN_LOAD_X(CH, r)                       \
         WN_LOAD_W(CH)                                                                            \
     }
+    // timing experiment (PP_CONV_DBG bits 8..14): delay the second workgroup of every CU by n x 512 cycles so the two
+    // resident workgroups run out of phase (staging of one under the MFMA phase of the other)
+    if ((p.dbg >> 8) && blockIdx.x >= (gridDim.x >> 1))
+        for (int i = 0; i < ((p.dbg >> 8) & 0x7F); ++i) __builtin_amdgcn_s_sleep(8);
     int cur_frame = -1;
     {
         const int lin0 = xk * per + xj;
@@ -774,8 +784,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             if constexpr (PP_WINO_DIAG & 8) {
                 asm volatile("" ::"v"(a[s_ % AD].x), "v"(a[s_ % AD].y), "v"(vcur));
             } else {
+                if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(PP_WINO_PRIO);
                 acc[0][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].x, vcur, acc[0][xi], 0, 0, 0);
                 acc[1][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].y, vcur, acc[1][xi], 0, 0, 0);
+                if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1550,11 +1562,11 @@ Variant make_variant()
 }
 
 template <int TWT, int WM, int WN, int BTX, int KC>
-Variant make_wino()
+Variant make_wino(bool roofline_layer)
 {
     using C = WinoCfg<TWT, WM, WN, BTX, KC>;
     Variant v;
-    v.kern = wino_mfma<TWT, WM, WN, BTX, KC>;
+    v.kern = roofline_layer ? wino_mfma<TWT, WM, WN, BTX, KC, 1> : wino_mfma<TWT, WM, WN, BTX, KC, 0>;
     v.bm = C::BM; v.bmp = C::BMP; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
     v.waves = WM * WN; v.pairs = 2 * 16;
     v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
@@ -1656,7 +1668,7 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0)
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false)
 {
     const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
     if (kind == 2) {
@@ -1676,17 +1688,17 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
     } else {
         conv_menu<3, 1, 8, EPI_PLAIN>(menu);
         //                     TWT WM WN BTX KC      output patch, rows
-        menu.push_back(make_wino<8, 1, 4, 1, 8>());  // 16x16 px, 32 rows
-        menu.push_back(make_wino<8, 1, 4, 2, 8>());  // 32x8 px, 32 rows
-        menu.push_back(make_wino<8, 2, 2, 1, 8>());  // 16x8 px, 64 rows
-        menu.push_back(make_wino<8, 2, 4, 1, 8>());  // 16x16 px, 64 rows, 8 waves
-        menu.push_back(make_wino<4, 1, 4, 2, 8>());  // 16x16 px, 32 rows
-        menu.push_back(make_wino<4, 2, 2, 1, 8>());  // 8x16 px, 64 rows
-        menu.push_back(make_wino<4, 2, 4, 2, 8>());  // 16x16 px, 64 rows, 8 waves
-        menu.push_back(make_wino<4, 1, 4, 1, 8>());  // 8x32 px, 32 rows
-        menu.push_back(make_wino<2, 1, 4, 2, 8>());  // 8x32 px (2x8-tile N-tiles), 32 rows
-        menu.push_back(make_wino<8, 1, 4, 1, 4>());
-        menu.push_back(make_wino<4, 1, 4, 2, 4>());
+        menu.push_back(make_wino<8, 1, 4, 1, 8>(roofline_layer));  // 16x16 px, 32 rows
+        menu.push_back(make_wino<8, 1, 4, 2, 8>(roofline_layer));  // 32x8 px, 32 rows
+        menu.push_back(make_wino<8, 2, 2, 1, 8>(roofline_layer));  // 16x8 px, 64 rows
+        menu.push_back(make_wino<8, 2, 4, 1, 8>(roofline_layer));  // 16x16 px, 64 rows, 8 waves
+        menu.push_back(make_wino<4, 1, 4, 2, 8>(roofline_layer));  // 16x16 px, 32 rows
+        menu.push_back(make_wino<4, 2, 2, 1, 8>(roofline_layer));  // 8x16 px, 64 rows
+        menu.push_back(make_wino<4, 2, 4, 2, 8>(roofline_layer));  // 16x16 px, 64 rows, 8 waves
+        menu.push_back(make_wino<4, 1, 4, 1, 8>(roofline_layer));  // 8x32 px, 32 rows
+        menu.push_back(make_wino<2, 1, 4, 2, 8>(roofline_layer));  // 8x32 px (2x8-tile N-tiles), 32 rows
+        menu.push_back(make_wino<8, 1, 4, 1, 4>(roofline_layer));
+        menu.push_back(make_wino<4, 1, 4, 2, 4>(roofline_layer));
         if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
         if (cin == 128) menu.push_back(make_wres<128, 1, 1>()); // 128 KB slab: 128 ch x 16 rows
     }
@@ -2004,7 +2016,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d b%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind,
              ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
     std::vector<Variant> menu;
-    layer_menu(L.kind, L.stride, L.up, menu, L.cin);
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)

@@ -3,22 +3,20 @@ pass each, per forced tiling).
 
 usage: hbm_traffic.py <out.json> <frames> <algorithmic_bytes> <tiling>=<dir_fetch>,<dir_write> [...]
 
-The roofline kernel is the 3x3 s1 64->64 layer at 400x400: of all wino_mfma launches in a pass it has the
-largest grid.  Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950
+The roofline layer (3x3 s1 64->64 at 400x400) runs its own copy of the Winograd kernel (symbol
+`wino_mfma<..., 1>`), so its launches are the rows of that symbol.  Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950
 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so the corrected figure doubles it (both
 are written; the kernel reads dwords, for which the guide calls the absolute uncalibrated, so the true read
 side lies between the two).
 """
-import csv, glob, json, sys
+import os, csv, glob, json, re, sys
 
 
 def rows(d, counter):
-    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
-    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'wino_mfma' in r['Kernel_Name']]
+    f = max(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
+    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and re.search(r'wino_mfma<[^>]*, 1>', r['Kernel_Name'])]
     if not rs:
-        raise SystemExit(f'no {counter} rows for wino_mfma in {f}')
-    g = max(int(r['Grid_Size']) for r in rs)
-    rs = [r for r in rs if int(r['Grid_Size']) == g]
+        raise SystemExit(f'no {counter} rows for the roofline copy wino_mfma<..., 1> in {f}')
     vals = [float(r['Counter_Value']) for r in rs]
     return sum(vals) / len(vals), len(vals), rs[0]['Kernel_Name'].replace('(anonymous namespace)::', '')
 

@@ -1,5 +1,5 @@
-import csv, collections, sys, glob
-f = sorted(glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True))[-1]
+import os, csv, collections, sys, glob
+f = max(glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)

@@ -1,5 +1,5 @@
-import csv, sys, glob
-f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True))[-1]
+import os, csv, sys, glob
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)
 frames = float(sys.argv[2]) if len(sys.argv) > 2 else 35
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)

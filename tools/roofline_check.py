@@ -2,20 +2,19 @@
 
 usage: roofline_check.py <rocprof_dir> <bench_json_of_that_run>
 
-The roofline kernel (3x3 s1 64->64 at 400x400) shares its template instance with other layers when the tuner
-picks the same tiling for them, so the trace rows are filtered to the launches with the largest grid of that
-symbol (the 400x400 layer) and only the timed steps (the last `launches` of them).
+The roofline layer (3x3 s1 64->64 at 400x400) runs its own copy of the Winograd kernel (template argument
+ROOFLINE = 1: symbol `wino_mfma<..., 1>`), so its launches are exactly the rows of that symbol; only the timed
+steps are compared (the last `launches` of them).
 """
-import csv, glob, json, sys
+import os, csv, glob, json, sys
 
 d, bj = sys.argv[1], sys.argv[2]
 b = json.loads(open(bj).read().strip().splitlines()[-1])
 r = b['roofline']
-f = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))[-1]
-rows = [x for x in csv.DictReader(open(f)) if 'wino_mfma' in x['Kernel_Name']]
-gs = lambda x: int(x['Grid_Size_X']) * int(x['Grid_Size_Y']) * int(x['Grid_Size_Z'])
-g = max(gs(x) for x in rows)
-rows = [x for x in rows if gs(x) == g]
+f = max(glob.glob(d + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
+import re
+rows = [x for x in csv.DictReader(open(f)) if re.search(r'wino_mfma<[^>]*, 1>', x['Kernel_Name'])]
+g = int(rows[0]['Grid_Size_X']) * int(rows[0]['Grid_Size_Y']) * int(rows[0]['Grid_Size_Z'])
 rows.sort(key=lambda x: int(x['Start_Timestamp']))
 rows = rows[-r['launches']:]
 dur = [(int(x['End_Timestamp']) - int(x['Start_Timestamp'])) / 1e6 for x in rows]
