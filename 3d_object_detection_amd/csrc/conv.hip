@@ -309,14 +309,22 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         }                                                                                        \
     }
 
-    PP_LOAD_CHUNK(0)
+    // One register set holds the NEXT chunk: it is written to the other LDS buffer right AFTER the barrier that opens a
+    // chunk (its loads were issued a whole chunk earlier, so the wait is free), and the loads of chunk ch+2 are
+    // re-issued at once -- they have the MFMA steps of this chunk plus the barrier to land.  (Writing at the END of
+    // the chunk, as the first version did, gave the loads only the chunk's own MFMA time and exposed the rest.)
+    if (nchunk > 0) PP_LOAD_CHUNK(0)
     __syncthreads(); // scl/shl visible
-    PP_STORE_CHUNK(0, 0)
+    if (nchunk > 0) PP_STORE_CHUNK(0, 0)
+    if (nchunk > 1 && !(p.dbg & 1)) PP_LOAD_CHUNK(1)
     __syncthreads();
 
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunk && !(p.dbg & 1)) PP_LOAD_CHUNK(ch + 1)
+        if (ch + 1 < nchunk && !(p.dbg & 1)) {
+            PP_STORE_CHUNK(ch + 1, buf ^ 1)
+            if (ch + 2 < nchunk) PP_LOAD_CHUNK(ch + 2)
+        }
         const float* ib = il + buf * C::LDS_IN;
         const float* wb = wl + buf * C::LDS_W;
         // Operand reads run ONE STEP AHEAD of the MFMAs that consume them (two register sets, order
@@ -346,7 +354,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
             __builtin_amdgcn_sched_barrier(0);
         });
 #undef PP_LOAD_OPS
-        if (ch + 1 < nchunk && !(p.dbg & 1)) PP_STORE_CHUNK(ch + 1, buf ^ 1)
         if (!(p.dbg & 8)) __syncthreads();
     }
 
@@ -1213,7 +1220,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 {
     constexpr int BM = MT * 16;
     constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
-    constexpr int PD = 8; // B-operand ring depth (steps in flight); even, and K % (4 * PD) == 0
+    constexpr int PD = (MT >= 8) ? 4 : 8; // B-operand ring depth (steps in flight); even, K % (4 * PD) == 0; 128 accumulator registers leave room for 4
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                         // [K][BMP]
     const int K = p.Cin;
@@ -1245,11 +1252,14 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
     const size_t plane = (size_t)HW;
     const int gw = wi * 8 + wave, gstride = nworkers * 8;
 
-    float ssum[MT][4], ssq[MT][4];
+    // per-row partial statistics: the plain epilogue keeps one pair per tile row, the pixel-shuffle epilogues fold a
+    // lane's 4 rows (the s^2 positions of ONE output channel) into slot 0 -- 4x fewer live registers at MT = 8
+    constexpr int SR = (EPI == EPI_PLAIN) ? 4 : 1;
+    float ssum[MT][SR], ssq[MT][SR];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+        for (int r = 0; r < SR; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
     int stat_frame = -1, pre_frame = -1;
     auto flush_stats = [&](int frame) {
         if (EPI == EPI_HEAD || !p.stat_acc || frame < 0) return;
@@ -1257,7 +1267,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < SR; ++r) {
                 float s = ssum[i][r], q = ssq[i][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) {
