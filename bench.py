@@ -248,7 +248,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "point-cloud frames/sec end-to-end (voxelise→NMS), eight_20cm, 1/2/4/8 MI355X",
+            "metric": f"point-cloud frames/sec end-to-end (voxelise→NMS), {args.config}, 1/2/4/8 MI355X",  # BASELINE.json's metric (default config eight_20cm)
             "value": round(world * K * NB / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
