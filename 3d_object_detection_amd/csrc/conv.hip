@@ -101,6 +101,7 @@ struct ConvP {
     size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
     size_t pre_fs, stat_fs;                        // doubles
     size_t aff_fs;                                 // floats between frames of pre_scale / pre_shift (0: shared)
+    unsigned long long* dbg_buf;                   // diagnostic builds only (PP_WINO_STAMP): stamp sums
     int nb;                                        // frames (persistent kernels loop over them; others use grid.z)
     // sparse BEV input of the first conv: pillar-index map [Hin*Win] (-1 = empty) + PFN rows [P][64]
     const int32_t* pmap;
@@ -471,6 +472,15 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 //   LDS pass, no extra barrier
 // * the OUTPUT transform is per lane too (the 16 positions of a tile are 16 accumulators of one lane)
 // ------------------------------------------------------------------------------------------
+#ifndef PP_WINO_STAMP
+#define PP_WINO_STAMP 0 // diagnostic build: s_memtime stamps around the segments of the Winograd chunk loop (tools/wino_stamp.sh)
+#endif
+#if PP_WINO_STAMP
+// stamp sums go to a caller-provided device buffer of 8 x u64 (pp_debug_set_stamp_buffer); cycles: [0] pre-steps, [1] steps, [2] barrier, [3] epilogue+tile setup, [4] chunks, [5] tiles
+#define WN_STAMP(VAR) { __builtin_amdgcn_sched_barrier(0); VAR = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WN_STAMP(VAR)
+#endif
 #ifndef PP_WINO_PRIO
 #define PP_WINO_PRIO 0 // s_setprio level around each MFMA pair of the Winograd loop (0: off)
 #endif
@@ -607,6 +617,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     // resident workgroups run out of phase (staging of one under the MFMA phase of the other)
     if ((p.dbg >> 8) && blockIdx.x >= (gridDim.x >> 1))
         for (int i = 0; i < ((p.dbg >> 8) & 0x7F); ++i) __builtin_amdgcn_s_sleep(8);
+#if PP_WINO_STAMP
+    unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0, sum_e1_ = 0, sum_pro_ = 0;
+#endif
     int cur_frame = -1;
     {
         const int lin0 = xk * per + xj;
@@ -616,6 +629,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         }
     }
     for (int lin = xk * per + xj; lin < lin_end; lin += nloc) {
+#if PP_WINO_STAMP
+    unsigned long long sp0_ = 0;
+    WN_STAMP(sp0_)
+#endif
     BlockId bid;
     bid.y = lin % ncb;
     bid.x = (lin / ncb) % ntile;
@@ -732,7 +749,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     if (nchunk > 1 && !(p.dbg & 1)) WN_LOAD_CHUNK(1)
     __syncthreads();
 
+#if PP_WINO_STAMP
+    { unsigned long long sx_ = 0; WN_STAMP(sx_) sum_pro_ += sx_ - sp0_; }
+#endif
     for (int ch = 0; ch < nchunk; ++ch) {
+#if PP_WINO_STAMP
+        unsigned long long st0_ = 0, st1_ = 0, st2_ = 0, st3_ = 0;
+        WN_STAMP(st0_)
+#endif
         const int buf = ch & 1;
         const float* ib = il + buf * C::LDS_IN;
         const float* wb = wl + buf * C::LDS_W;
@@ -759,6 +783,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             pp_steps<0, 16>([&](auto K) { WN_COLPASS(tq[0], draw, decltype(K)::value) });
         }
         vnext = WN_ROWPASS(tq[0], 0);
+        WN_STAMP(st1_)
         pp_steps<0, NSTEP>([&](auto S) {
             constexpr int s_ = decltype(S)::value;
             constexpr int c4 = s_ / 16, xi = s_ % 16;
@@ -799,7 +824,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             __builtin_amdgcn_sched_barrier(0);
         });
 #undef WN_LOAD_A
+        WN_STAMP(st2_)
         __syncthreads();
+#if PP_WINO_STAMP
+        WN_STAMP(st3_)
+        sum_pre_ += st1_ - st0_; sum_steps_ += st2_ - st1_; sum_bar_ += st3_ - st2_; n_chunks_ += 1; // flushed once per workgroup
+#endif
     }
 #undef WN_NORM_CHUNK
 #undef WN_WRITE_PIECE
@@ -807,6 +837,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #undef WN_COLPASS
 #undef WN_ROWPASS
 
+#if PP_WINO_STAMP
+    unsigned long long se0_ = 0;
+    WN_STAMP(se0_)
+#endif
     if (lin + nloc < lin_end) { // next tile's first chunk: in flight during the epilogue below
         set_load_tile(lin + nloc);
         if (!(p.dbg & 1)) WN_LOAD_CHUNK(0)
@@ -860,6 +894,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             }
         }
     }
+#if PP_WINO_STAMP
+    { unsigned long long sx_ = 0; WN_STAMP(sx_) sum_e1_ += sx_ - se0_; }
+#endif
     if (gstat) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -892,7 +929,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             atomicAdd(dst + 1, q);
         }
     }
+#if PP_WINO_STAMP
+    {
+        unsigned long long se1_ = 0;
+        WN_STAMP(se1_)
+        sum_epi_ += se1_ - se0_; n_tiles_ += 1;
+    }
+#endif
     } // tile loop
+#if PP_WINO_STAMP
+    if (tid == 0 && p.dbg_buf) {
+        atomicAdd(&p.dbg_buf[0], sum_pre_); atomicAdd(&p.dbg_buf[1], sum_steps_); atomicAdd(&p.dbg_buf[2], sum_bar_);
+        atomicAdd(&p.dbg_buf[3], sum_epi_); atomicAdd(&p.dbg_buf[4], n_chunks_); atomicAdd(&p.dbg_buf[5], n_tiles_);
+        atomicAdd(&p.dbg_buf[6], sum_e1_); atomicAdd(&p.dbg_buf[7], sum_pro_);
+    }
+#endif
 #undef WN_LOAD_X
 #undef WN_LOAD_W
 #undef WN_LOAD_CHUNK
@@ -1895,6 +1946,8 @@ __global__ void __launch_bounds__(320) norm_finalize(const double* __restrict__ 
 
 constexpr size_t STAT_FS = (size_t)24 * NREP * 320 * 2; // doubles of statistics per frame
 
+static unsigned long long* g_stamp_buf = nullptr; // diagnostic builds only
+
 int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, float* out, const float* res,
                 const NormRef& pre, double* stat_acc, int stat_C, int Hout, int Wout, hipStream_t stream,
                 float* out_box = nullptr, float* out_dir = nullptr, int B = 1, size_t out_fs = 0, size_t in_fs = 0,
@@ -1909,6 +1962,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.pre = pre.mode; p.pre_acc = pre.acc; p.pre_scale = pre.scale; p.pre_shift = pre.shift;
     p.pre_inv_n = pre.inv_n; p.eps = 1e-3f;
     p.stat_acc = stat_acc; p.stat_C = stat_C;
+    p.dbg_buf = g_stamp_buf;
     p.bias = (L.kind == 2 && L.var.wino == 3) ? net->head_bias_perm : net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
     p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
     { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
@@ -1943,6 +1997,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     if (v.wino == 1) { // persistent Winograd: two workgroups per CU (LDS and registers allow exactly two), a multiple of the 8 XCDs
         const int total = (int)grid.x * (int)grid.y * B;
         int g = 2 * net->num_cu;
+        if (p.dbg & 32) { g = net->num_cu; lds_bytes = 100 * 1024; } // timing experiment: ONE workgroup per CU (one wave per SIMD)
         if (g > total) g = total;
         g = (g + 7) & ~7;
         grid = dim3(g, 1, 1);
@@ -2482,3 +2537,7 @@ extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
         if (L.kind == 0 && L.level == 0 && L.stride == 1) return L.var.name;
     return "";
 }
+
+#if PP_WINO_STAMP
+extern "C" int pp_debug_set_stamp_buffer(unsigned long long* dev8) { g_stamp_buf = dev8; return 0; }
+#endif
