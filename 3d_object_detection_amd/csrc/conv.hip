@@ -1791,6 +1791,16 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
         const double c = model_cost(v, rows, Hout, Wout);
         if (c < best) { best = c; bv = v; }
     }
+    // Without on-device tuning (PP_AUTOTUNE=0) prefer what the tuner settles on for these layer kinds on MI355X;
+    // the cost model above only ranks the direct tilings.
+    const char* prefer = (kind == 0 && stride == 1) ? "wino tw8 w1x4 bx2 kc8"
+                         : (kind == 1 && up == 2)   ? "g1x1 m4 n4 e1"
+                         : (kind == 1 && up == 4)   ? "g1x1 m4 n4 e2"
+                         : (kind == 2)              ? "g1x1 m6 n4 e3"
+                                                    : nullptr;
+    if (prefer)
+        for (const Variant& v : menu)
+            if (variant_ok(v, rows) && !strcmp(v.name, prefer)) return v;
     return bv;
 }
 
