@@ -58,6 +58,7 @@ PROTOTYPES = {
     "pp_standup2d": (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
     "pp_nms": (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_int, c_f, c_p, c_p, ctypes.c_int, c_p]),
     "pp_rotated_iou": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, c_p]),
+    "pp_unpack_points": (ctypes.c_int, [c_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p, c_p]),
     "pp_rotated_iou_eval": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p]),
     "pp_eval_statistics": (ctypes.c_int, [c_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_p, c_p, c_p, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_int, c_p, c_p, c_p]),

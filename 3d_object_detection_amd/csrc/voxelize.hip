@@ -282,3 +282,59 @@ int pp_voxelize_group(pp_ctx* ctx, int b0, int g, const pp_in_group& in, hipStre
     PP_HIP(hipGetLastError());
     return 0;
 }
+
+// ---- sensor_msgs/PointCloud2 payload -> f32[n,4] (ros_node.py:55-59; sensor_msgs.point_cloud2.read_points) --------
+// One thread per (point, field): byte-wise load (fields may sit at any offset), endian swap, convert.  HBM-bound:
+// point_step bytes read, 16 bytes written per point.
+namespace {
+struct pp_pc2_fields { int32_t off[4]; int32_t dt[4]; };
+
+__global__ void __launch_bounds__(256) pc2_unpack(const uint8_t* __restrict__ data, int64_t n, int64_t width, int64_t row_step, int point_step,
+                                                  pp_pc2_fields f, int big_endian, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 4) return;
+    const int64_t i = t >> 2;
+    const int k = (int)(t & 3);
+    const uint8_t* src = data + (i / width) * row_step + (i % width) * point_step + f.off[k];
+    const int dt = f.dt[k];
+    const int nbytes = (dt == 1 || dt == 2) ? 1 : (dt == 3 || dt == 4) ? 2 : (dt == 8) ? 8 : 4;
+    uint64_t bits = 0;
+    for (int b = 0; b < nbytes; ++b) {
+        const uint64_t byte = src[b];
+        bits |= byte << (8 * (big_endian ? (nbytes - 1 - b) : b));
+    }
+    float val;
+    switch (dt) {
+    case 1: val = (float)(int8_t)bits; break;
+    case 2: val = (float)(uint8_t)bits; break;
+    case 3: val = (float)(int16_t)bits; break;
+    case 4: val = (float)(uint16_t)bits; break;
+    case 5: val = (float)(int32_t)bits; break;
+    case 6: val = (float)(uint32_t)bits; break;
+    case 8: val = (float)__longlong_as_double((long long)bits); break; // numpy .astype(float32): round to nearest
+    default: val = __uint_as_float((uint32_t)bits); break;
+    }
+    out[t] = val;
+}
+} // namespace
+
+extern "C" int pp_unpack_points(const void* data, int64_t n, int64_t width, int64_t row_step, int point_step, const int32_t* offs,
+                                const int32_t* dtypes, int big_endian, float* out, void* stream)
+{
+    if (n < 0 || width <= 0 || point_step <= 0 || row_step < 0 || !offs || !dtypes) return PP_E_ARG;
+    if (n == 0) return 0;
+    if (!data || !out) return PP_E_ARG;
+    pp_pc2_fields f;
+    for (int k = 0; k < 4; ++k) {
+        if (dtypes[k] < 1 || dtypes[k] > 8 || offs[k] < 0) return PP_E_ARG;
+        const int nb = (dtypes[k] <= 2) ? 1 : (dtypes[k] <= 4) ? 2 : (dtypes[k] == 8) ? 8 : 4;
+        if (offs[k] + nb > point_step) return PP_E_ARG;
+        f.off[k] = offs[k];
+        f.dt[k] = dtypes[k];
+    }
+    hipLaunchKernelGGL(pc2_unpack, dim3(pp_div_up(n * 4, 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)data, n, width, row_step,
+                       point_step, f, big_endian, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}

@@ -8,6 +8,7 @@
   annos_from_records(...)        device detection records -> KITTI-style annos    (inference.py:124-138,724-737)
   run_sequence(...)              clouds -> annos through pp_infer_batch, B frames per pass, one D2H per pass
   save_detections / load_detections   the `dt_info` pickle                        (train.py:264-265)
+  pointcloud2_to_points(msg)     sensor_msgs/PointCloud2 payload -> f32[N,4] on the device   (ros_node.py:55-59)
 
 Host-side glue only: the compute stays in libpp_hip.so (engine.Engine).
 """
@@ -125,3 +126,43 @@ def save_detections(path, dt_annos):
 def load_detections(path):
     with open(path, "rb") as f:
         return pickle.load(f)
+
+
+# sensor_msgs/PointField datatype codes
+_PC2_SIZES = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 4, 8: 8}
+
+
+def pointcloud2_to_points(msg, device=None):
+    """`np.asarray(list(pc2.read_points(msg)))[:, :4].astype(np.float32)` of the reference's ROS callback
+    (ros_node.py:55-59) as one H2D copy of the raw payload + one unpack kernel: the first four fields of the message
+    (in the message's field order, whatever their types, offsets and padding) become f32[N,4] on the device.
+    `msg` is any object with the PointCloud2 attributes (data, fields[name/offset/datatype/count], point_step, row_step,
+    width, height, is_bigendian); rospy itself is not needed."""
+    import ctypes
+    from . import _lib
+    fields = sorted(msg.fields, key=lambda f: f.offset)  # read_points orders the struct by offset
+    if len(fields) < 4:
+        raise ValueError("PointCloud2 message has fewer than 4 fields")
+    first = fields[:4]
+    for f in first:
+        if getattr(f, "count", 1) != 1:
+            raise ValueError(f"field {f.name}: count != 1 is not supported")
+        if f.datatype not in _PC2_SIZES:
+            raise ValueError(f"field {f.name}: unknown datatype {f.datatype}")
+    n = int(msg.width) * int(msg.height)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    raw = np.frombuffer(bytes(msg.data), dtype=np.uint8)
+    need = (int(msg.height) - 1) * int(msg.row_step) + int(msg.width) * int(msg.point_step)
+    if raw.size < need:
+        raise ValueError(f"PointCloud2 data holds {raw.size} bytes, {need} needed")
+    buf = torch.from_numpy(raw.copy()).to(dev, non_blocking=True)
+    offs = (ctypes.c_int32 * 4)(*[int(f.offset) for f in first])
+    dts = (ctypes.c_int32 * 4)(*[int(f.datatype) for f in first])
+    with torch.cuda.device(dev):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.load().pp_unpack_points(buf.data_ptr(), n, int(msg.width), int(msg.row_step), int(msg.point_step), offs, dts,
+                                                int(bool(msg.is_bigendian)), out.data_ptr(), s), None, "pp_unpack_points")
+    return out

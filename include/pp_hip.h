@@ -122,6 +122,15 @@ int pp_standup2d(const float* corners /*[n,4,2]*/, float* boxes /*[n,4]*/, int64
 int pp_nms(const float* dets, int n, int stride, float thresh, int32_t* keep, int32_t* nkeep, int rotate, void* stream);
 int pp_rotated_iou(const float* boxes_a /*[n,5]*/, const float* boxes_b /*[m,5]*/, float* iou /*[n,m]*/, int n, int m, void* stream);
 
+/* ---- ROS ingest ----
+ * pp_unpack_points replaces `np.asarray(list(pc2.read_points(msg)))[:, :4].astype(np.float32)` (ros_node.py:55-59):
+ * the first four fields of a sensor_msgs/PointCloud2 payload -> f32[n,4] on the device.  `data` is the message's byte
+ * buffer in device memory; point i sits at (i / width) * row_step + (i % width) * point_step; offs/dtypes are HOST
+ * arrays of the four fields' byte offsets and PointField datatype codes (1 INT8, 2 UINT8, 3 INT16, 4 UINT16,
+ * 5 INT32, 6 UINT32, 7 FLOAT32, 8 FLOAT64). */
+int pp_unpack_points(const void* data, int64_t n, int64_t width, int64_t row_step, int point_step, const int32_t* offs /*[4]*/,
+                     const int32_t* dtypes /*[4]*/, int big_endian, float* out /*[n,4]*/, void* stream);
+
 /* ---- evaluation ----
  * pp_rotated_iou_eval replaces rotate_iou_gpu_eval (eval/iou.py:540-638): out[i,j] for box i and query j with
  * criterion -1: IoU, 0: inter / area(query), 1: inter / area(box), 2: intersection area -- the reference's kernel
