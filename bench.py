@@ -231,6 +231,8 @@ def main():
     for i in range(K):
         step(i, i)
     if dist:
+        for s_ in streams:  # the one collective of the path follows the compute it gathers (the steps ran on side streams)
+            torch.cuda.current_stream(dev).wait_stream(s_)
         shard.gather_detections(det.view(K * NB, rows, 9), cnt.view(K * NB, 1 + 8))
     torch.cuda.synchronize()
     if dist:
