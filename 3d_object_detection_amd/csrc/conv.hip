@@ -1758,6 +1758,7 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         menu.push_back(make_wino<4, 2, 4, 2, 8>(roofline_layer));  // 16x16 px, 64 rows, 8 waves
         menu.push_back(make_wino<4, 1, 4, 1, 8>(roofline_layer));  // 8x32 px, 32 rows
         menu.push_back(make_wino<2, 1, 4, 2, 8>(roofline_layer));  // 8x32 px (2x8-tile N-tiles), 32 rows
+        // (8-wave 32-row tilings, WN = 8, were tried: 6-15 % slower than their 4-wave twins -- two lock-stepped waves per SIMD)
         menu.push_back(make_wino<8, 1, 4, 1, 4>(roofline_layer));
         menu.push_back(make_wino<4, 1, 4, 2, 4>(roofline_layer));
         if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
@@ -2006,7 +2007,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     }
     if (v.wino == 1) { // persistent Winograd: two workgroups per CU (LDS and registers allow exactly two), a multiple of the 8 XCDs
         const int total = (int)grid.x * (int)grid.y * B;
-        int g = 2 * net->num_cu;
+        int g = (v.threads >= 512 ? 1 : 2) * net->num_cu; // 8-wave workgroups fill a CU's registers alone
         if (p.dbg & 32) { g = net->num_cu; lds_bytes = 100 * 1024; } // timing experiment: ONE workgroup per CU (one wave per SIMD)
         if (g > total) g = total;
         g = (g + 7) & ~7;
