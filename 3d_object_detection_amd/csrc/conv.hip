@@ -59,6 +59,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
+// Sum over the 16 lanes that share lane >> 4 (one row of the 16x16 MFMA tile = one DPP row), on the VALU: two quad
+// permutes, row_half_mirror, row_mirror.  After each step all lanes of the merged group hold the same value, so the
+// result is bit-identical to the xor-shuffle butterfly (1, 2, 4, 8) it replaces -- which hipcc turned into four
+// dependent ds_bpermute per value (64 LDS round trips per Winograd tile and wave).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_f32<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v); // row_half_mirror
+    v += dpp_f32<0x140>(v); // row_mirror
+    return v;
+}
+
 constexpr int NREP = 8; // replicated statistics accumulators (spreads atomic contention)
 
 // compile-time for: f(integral_constant<int, I>) for I in [B, E)
@@ -428,11 +446,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = ssum[i][r], q = ssq[i][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o);
-                    q += __shfl_xor(q, o);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
                 if (m == 0) {
                     const int lr = wm * MT * 16 + i * 16 + kq * 4 + r; // local row
                     red[(wn * C::BM + lr) * 2] = s;
@@ -954,11 +969,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = ssum[i][r], q = ssq[i][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o);
-                    q += __shfl_xor(q, o);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
                 if (m == 0) {
                     const int lr = wm * MT * 16 + i * 16 + kq * 4 + r;
                     red[(wn * C::BM + lr) * 2] = s;
@@ -1081,11 +1093,8 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = ssum[i][r], q = ssq[i][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o);
-                    q += __shfl_xor(q, o);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
                 if (m == 0) {
                     const int row = co0 + i * 16 + kq * 4 + r;
                     atomicAdd(base + (size_t)row * 2, (double)s);
@@ -1371,11 +1380,8 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
                 float s = ssum[i][r], q = ssq[i][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o);
-                    q += __shfl_xor(q, o);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
                 const int row = co0 + i * 16 + kq * 4 + r;
                 int ch = row;
                 bool lead = (m == 0);
