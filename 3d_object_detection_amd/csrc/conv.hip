@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 #define WN_STAMP(VAR)
 #endif
 #ifndef PP_WINO_PRIO
-#define PP_WINO_PRIO 0 // s_setprio level around each MFMA pair of the Winograd loop (0: off)
+#define PP_WINO_PRIO 1 // s_setprio level of the NON-MFMA segments (chunk opening, epilogue, tile prologue) of the Winograd loop (0: off)
 #endif
 #ifndef PP_WINO_DIAG
 #define PP_WINO_DIAG 0 // timing-only ablations of the Winograd loop (wrong results): 1 no transform, 2 no raw reads, 4 no A reads, 8 no MFMA
@@ -778,6 +778,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
         float draw[16], tq[2][16];
         float2 a[AD];
         float vcur, vnext;
+        if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(PP_WINO_PRIO); // the short non-MFMA segments first: back to the matrix pipe sooner
         WN_READ_RAW(draw, 0)
 #define WN_LOAD_A(S)                                                                             \
     {                                                                                            \
@@ -798,6 +799,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             pp_steps<0, 16>([&](auto K) { WN_COLPASS(tq[0], draw, decltype(K)::value) });
         }
         vnext = WN_ROWPASS(tq[0], 0);
+        if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(0);
         WN_STAMP(st1_)
         pp_steps<0, NSTEP>([&](auto S) {
             constexpr int s_ = decltype(S)::value;
@@ -831,10 +833,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
             if constexpr (PP_WINO_DIAG & 8) {
                 asm volatile("" ::"v"(a[s_ % AD].x), "v"(a[s_ % AD].y), "v"(vcur));
             } else {
-                if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(PP_WINO_PRIO);
                 acc[0][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].x, vcur, acc[0][xi], 0, 0, 0);
                 acc[1][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ % AD].y, vcur, acc[1][xi], 0, 0, 0);
-                if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -852,6 +852,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #undef WN_COLPASS
 #undef WN_ROWPASS
 
+    if (PP_WINO_PRIO) __builtin_amdgcn_s_setprio(PP_WINO_PRIO);
 #if PP_WINO_STAMP
     unsigned long long se0_ = 0;
     WN_STAMP(se0_)
