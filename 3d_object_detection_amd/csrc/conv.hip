@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
+        __builtin_amdgcn_s_setprio(1);
         if (ch + 1 < nchunk && !(p.dbg & 1)) {
             PP_STORE_CHUNK(ch + 1, buf ^ 1)
             if (ch + 2 < nchunk) PP_LOAD_CHUNK(ch + 2)
@@ -360,6 +361,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
         _Pragma("unroll") for (int j = 0; j < NT; ++j) b[SET][j] = ib[toff[j] + c4_ * 4 * C::CS + tapoff_]; \
     }
         PP_LOAD_OPS(0, 0)
+        __builtin_amdgcn_s_setprio(0);
         pp_steps<0, NS>([&](auto S) {
             constexpr int s_ = decltype(S)::value;
             constexpr int cur = s_ & 1;
@@ -375,6 +377,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 #undef PP_LOAD_OPS
         if (!(p.dbg & 8)) __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(1); // epilogue
 
     // ---- epilogue ----
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) gout[0] = 1.f; return; }
@@ -1357,6 +1360,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         for (int e = tid; e < K * BMP / 4; e += 512) d[e] = g[e];
     }
     __syncthreads(); // the only workgroup barrier
+    __builtin_amdgcn_s_setprio(1); // item prologue / epilogue run at raised priority, the MFMA stream at 0
 
     const int HW = p.Hout * p.Wout;
     const int items_per_frame = (HW + NT * 16 - 1) / (NT * 16);
@@ -1480,6 +1484,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         // that no step carries a run-time condition.
         float a[2][MT], b[2][NT];
         G1_PREP(0, 0, 0)
+        __builtin_amdgcn_s_setprio(0); // the MFMA stream yields issue slots to the other wave's short non-MFMA segments
         int sb = 0;
         for (; sb < nsteps - PD; sb += PD) {
 #pragma unroll
@@ -1497,6 +1502,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             G1_MFMAS(u & 1)
         }
 
+        __builtin_amdgcn_s_setprio(1);
         if (item + gstride < total) { // next item's first quads, ahead of this item's stores
             set_load_item(item + gstride);
 #pragma unroll
