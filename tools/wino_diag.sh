@@ -1,4 +1,8 @@
 # timing-only ablations of the Winograd loop (developer tool; results of these builds are wrong by design)
+# build the ablation libraries first, in 3d_object_detection_amd/csrc (k = bit set of PP_WINO_DIAG, see conv.hip):
+#   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -DPP_WINO_DIAG=$k -c conv.hip -o _build/conv_diag$k.o
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o _build/libpp_diag$k.so _build/{pp_api,voxelize,anchor_mask,pfn_scatter,postprocess,frame,eval_host}.o _build/conv_diag$k.o
+# tools/wino_stamp.py needs the same with -DPP_WINO_STAMP=1 into _build/libpp_stamp.so
 R=$PWD
 for k in ${DIAGS:-0 15}; do
   for dbg in ${DBGS:-0 1 4 5}; do
