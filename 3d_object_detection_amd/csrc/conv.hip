@@ -1518,6 +1518,11 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             // them out of the item loop and spills them around the MFMA loop; recomputing per item is ~free
             int kq_e = kq;
             asm volatile("" : "+v"(kq_e));
+            // pixel-shuffle epilogues: pxb is a multiple of 4, so with Wout % 4 == 0 (workgroup-uniform test; every map of
+            // the shipped configurations) the lane's 4 pixels lie in one row and one division per item does
+            const bool row4 = (p.Wout & 3) == 0;
+            const int py_ = pxb / p.Wout, px_ = pxb - py_ * p.Wout;
+            (void)row4; (void)py_; (void)px_;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row0 = co0 + i * 16 + kq_e * 4;
@@ -1535,8 +1540,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                     const size_t W2 = (size_t)p.Wout * 2;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const int px = pxb + j;
-                        const int y = px / p.Wout, xx = px - y * p.Wout;
+                        const int y = row4 ? py_ : (pxb + j) / p.Wout, xx = row4 ? px_ + j : (pxb + j) - y * p.Wout;
                         const f32x4 v = acc[i][j];
                         float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * y) * W2 + 2 * xx;
                         *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
@@ -1549,8 +1553,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                     const size_t W4o = (size_t)p.Wout * 4;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const int px = pxb + j;
-                        const int y = px / p.Wout, xx = px - y * p.Wout;
+                        const int y = row4 ? py_ : (pxb + j) / p.Wout, xx = row4 ? px_ + j : (pxb + j) - y * p.Wout;
                         const f32x4 v = acc[i][j];
                         float* o = gout + (size_t)co * plane * 16 + (size_t)(4 * y + dy) * W4o + 4 * xx;
                         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
