@@ -499,6 +499,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 #else
 #define WN_STAMP(VAR)
 #endif
+#ifndef PP_WINO_AD
+#define PP_WINO_AD 6 // steps the A-operand LDS reads run ahead of their MFMA pair
+#endif
 #ifndef PP_WINO_PRIO
 #define PP_WINO_PRIO 1 // s_setprio level of the NON-MFMA segments (chunk opening, epilogue, tile prologue) of the Winograd loop (0: off)
 #endif
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     constexpr int WSTEPS = (NPIECE + PER - 1) / PER;
     static_assert(WSTEPS + LOAD_STEPS <= NSTEP, "staging does not fit the chunk's MFMA steps");
     // A operands run AD steps ahead of their MFMAs (a step is only 2 MFMAs = 64 cycles; LDS latency is 2-3x that)
-    constexpr int AD = 6;
+    constexpr int AD = PP_WINO_AD;
 
     // chunk 0 of this tile was requested before the previous tile's epilogue (or ahead of the loop)
     __syncthreads(); // scl / shl visible
@@ -1241,7 +1244,7 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
                 }
             }
             // 16 positions x MT x NT MFMAs, A operands AD steps ahead
-            constexpr int AD = 6;
+            constexpr int AD = PP_WINO_AD;
             float a[AD][MT];
             const float* ub = ul + (size_t)(ch * C::KC) * C::BM;
 #define WR_LOAD_A(XI)                                                                            \
