@@ -499,6 +499,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma(const ConvP p)
 #else
 #define WN_STAMP(VAR)
 #endif
+#ifndef PP_WINO_PER
+#define PP_WINO_PER 2 // minimum LDS write pieces per MFMA step of the staging pipeline (2: +0.3 % over 1, 4: -1.5 %)
+#endif
 #ifndef PP_WINO_AD
 #define PP_WINO_AD 6 // steps the A-operand LDS reads run ahead of their MFMA pair
 #endif
@@ -757,7 +760,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
     constexpr int NSTEP = NQ * 16;
     constexpr int NPIECE = C::PR * KC + C::WR;                       // LDS write pieces of one chunk
     constexpr int LOAD_STEPS = C::PR + 1;                            // re-issue: one x row or the weights per step
-    constexpr int PER = (NPIECE + (NSTEP - LOAD_STEPS - 1) - 1) / (NSTEP - LOAD_STEPS - 1); // write pieces per step
+    constexpr int PER_MIN = (NPIECE + (NSTEP - LOAD_STEPS - 1) - 1) / (NSTEP - LOAD_STEPS - 1);
+    constexpr int PER = PER_MIN > PP_WINO_PER ? PER_MIN : PP_WINO_PER; // write pieces per step (more per step = the next loads go out earlier)
     constexpr int WSTEPS = (NPIECE + PER - 1) / PER;
     static_assert(WSTEPS + LOAD_STEPS <= NSTEP, "staging does not fit the chunk's MFMA steps");
     // A operands run AD steps ahead of their MFMAs (a step is only 2 MFMAs = 64 cycles; LDS latency is 2-3x that)
