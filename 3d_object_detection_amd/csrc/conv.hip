@@ -1868,7 +1868,7 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
     }
     // Without on-device tuning (PP_AUTOTUNE=0) prefer what the tuner settles on for these layer kinds on MI355X;
     // the cost model above only ranks the direct tilings.
-    const char* prefer = (kind == 0 && stride == 1) ? "wino tw8 w1x4 bx2 kc8"
+    const char* prefer = (kind == 0 && stride == 1) ? "wino tw8 w1x4 bx1 kc8"
                          : (kind == 1 && up == 2)   ? "g1x1 m4 n4 e1"
                          : (kind == 1 && up == 4)   ? "g1x1 m4 n4 e2"
                          : (kind == 2)              ? "g1x1 m6 n4 e3"
@@ -2156,7 +2156,7 @@ void tune_cache_save()
 // Measure every admissible tiling of one layer on the device (1 warm-up + 3 timed launches with
 // hipEvents) and keep the fastest.  Weights are really packed for each candidate, the prologue /
 // statistics epilogue run as in production.
-constexpr int TUNE_FRAMES = 8;          // frames per timed launch of the tuner
+constexpr int TUNE_FRAMES = 16;         // frames per timed launch of the tuner (= the default production batch)
 constexpr size_t TUNE_OUT_FS = 0, TUNE_IN_FS = 0; // 0: natural per-frame strides
 
 int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose)

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/prof.json 2> $R/gpurun_out/prof.err
 unset PP_TUNE_CACHE
 i=0
-for T in "wino tw8 w1x4 bx1 kc8" "wino tw8 w1x4 bx2 kc8" "wino tw4 w1x4 bx2 kc8"; do
+for T in "wino tw8 w1x4 bx1 kc4" "wino tw8 w1x4 bx1 kc8" "wino tw8 w1x4 bx2 kc8" "wino tw4 w1x4 bx2 kc8"; do
   export PP_FORCE_VARIANT="$T"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmcf_$i -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $R/gpurun_out/pmcf_$i.json 2> $R/gpurun_out/pmcf_$i.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_$i -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $R/gpurun_out/pmcw_$i.json 2> $R/gpurun_out/pmcw_$i.err
