@@ -106,3 +106,32 @@ def test_synthetic_cloud_shapes(synth):
     assert np.array_equal(a, b)
     sd = synth.seeded_state_dict(0)
     assert len([k for k in sd]) == 30 and sd["rpn.deconv3.0.weight"].shape == (256, 128, 4, 4)
+
+
+def test_stateless_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation of the context-free C entry points happens before any HIP call, so it can be checked on a
+    CPU-only box: every call below must return a non-zero code and must not crash."""
+    import ctypes
+    lib = load_pkg("_lib").load()
+    i4 = (ctypes.c_int32 * 4)(0, 4, 8, 12)
+    f32 = (ctypes.c_int32 * 4)(7, 7, 7, 7)
+    bad_dt = (ctypes.c_int32 * 4)(7, 7, 9, 7)
+    past = (ctypes.c_int32 * 4)(0, 4, 8, 14)
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # pp_unpack_points: negative count, zero width, unknown datatype, field running past point_step, null table
+    assert lib.pp_unpack_points(p, -1, 1, 16, 16, i4, f32, 0, p, None) != 0
+    assert lib.pp_unpack_points(p, 4, 0, 16, 16, i4, f32, 0, p, None) != 0
+    assert lib.pp_unpack_points(p, 4, 4, 64, 16, i4, bad_dt, 0, p, None) != 0
+    assert lib.pp_unpack_points(p, 4, 4, 64, 16, past, f32, 0, p, None) != 0
+    assert lib.pp_unpack_points(p, 4, 4, 64, 16, None, f32, 0, p, None) != 0
+    assert lib.pp_unpack_points(None, 0, 4, 64, 16, i4, f32, 0, None, None) == 0  # empty cloud: nothing to do
+    # pp_rotated_iou_eval: criterion outside -1..2, negative sizes; empty inputs are fine
+    assert lib.pp_rotated_iou_eval(p, p, p, 1, 1, 3, None) != 0
+    assert lib.pp_rotated_iou_eval(p, p, p, -1, 1, -1, None) != 0
+    assert lib.pp_rotated_iou_eval(None, None, None, 0, 5, -1, None) == 0
+    # pp_eval_statistics: missing outputs / inputs
+    out = (ctypes.c_int64 * 3)()
+    assert lib.pp_eval_statistics(None, 0, 2, 2, None, None, None, 0.5, 0.0, 0, out, None, None) != 0
+    assert lib.pp_eval_statistics(None, 0, 0, 0, None, None, None, 0.5, 0.0, 0, None, None, None) != 0
+    assert lib.pp_eval_statistics(None, 0, 0, 0, None, None, None, 0.5, 0.0, 0, out, None, None) == 0 and list(out) == [0, 0, 0]
