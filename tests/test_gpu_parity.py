@@ -391,3 +391,43 @@ def test_batched_frames_equal_single_frames(fw, synth):
         k = int(c1[0])
         np.testing.assert_allclose(det_b[i, :k].cpu().numpy(), d1[:k].cpu().numpy(), rtol=0, atol=1e-5)
     assert int(cnt_b[2, 0]) == 0
+
+
+def test_full_size_batch_properties(fw, synth):
+    """BASELINE.json's metric workload (eight_20cm, 800x800 BEV) at a batch that spans TWO stage groups
+    (PP_GROUP = 16 frames per integer-stage launch -> 18 frames = 16 + 2), ragged clouds and one empty
+    frame.  Size-independent properties instead of the (too slow) oracle: frame independence (each frame of
+    the batch equals its own pp_infer_frame; counts bit-exact, boxes within 1e-5 -- the per-frame InstanceNorm
+    statistics are fp64 atomics whose order may move the last fp32 bit), permutation equivariance, and
+    repeatability of the same call."""
+    eng_mod = load_pkg("engine")
+    cfg = make_cfg(synth, "eight_20cm")
+    fw["vg"].VoxelGenerator(cfg)
+    eng = eng_mod.Engine(cfg, max_batch=18)
+    eng.load_state_dict(synth.seeded_state_dict(5, cls_bias=-3.0))
+    sizes = [None, 90000, 30000, 7, 120000, 1] + [None] * 10 + [50000, 0]
+    clouds = []
+    for i, n in enumerate(sizes):
+        pts = synth.lidar_cloud("eight_20cm", seed=40 + i, n_points=n) if n != 0 else np.zeros((0, 4), np.float32)
+        clouds.append(torch.from_numpy(pts).cuda())
+    det_b, cnt_b = eng.infer_batch(clouds)
+    det_b, cnt_b = det_b.cpu().numpy().copy(), cnt_b.cpu().numpy().copy()
+    assert int(cnt_b[17, 0]) == 0
+    assert (cnt_b[:3, 0] > 0).all()
+    # frame independence, on both sides of the group boundary
+    for i in (0, 3, 5, 15, 16, 17):
+        d1, c1 = eng.infer_frame(clouds[i])
+        assert np.array_equal(c1.cpu().numpy()[:4], cnt_b[i][:4]), i
+        k = int(c1[0])
+        np.testing.assert_allclose(det_b[i, :k], d1[:k].cpu().numpy(), rtol=0, atol=1e-5)
+    # permutation equivariance: reversing the frame order reverses the outputs
+    det_r, cnt_r = eng.infer_batch(clouds[::-1])
+    det_r, cnt_r = det_r.cpu().numpy(), cnt_r.cpu().numpy()
+    for i in range(18):
+        assert np.array_equal(cnt_r[17 - i][:4], cnt_b[i][:4]), i
+        k = int(cnt_b[i, 0])
+        np.testing.assert_allclose(det_r[17 - i, :k], det_b[i, :k], rtol=0, atol=1e-5)
+    # the same call again gives the same detections
+    det_2, cnt_2 = eng.infer_batch(clouds)
+    assert np.array_equal(cnt_2.cpu().numpy()[:, :4], cnt_b[:, :4])
+    np.testing.assert_allclose(det_2.cpu().numpy(), det_b, rtol=0, atol=1e-5)
