@@ -1545,15 +1545,29 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                 } else if (EPI == EPI_UP2) {
                     const int co = row0 >> 2;
                     const size_t W2 = (size_t)p.Wout * 2;
+                    if (row4) {
+                        // the lane's 4 pixels are 8 consecutive floats of output rows 2y and 2y+1: two dwordx4 per row,
+                        // 512 contiguous bytes per 16 lanes (the per-pixel float2 stores left 8 of every 32 bytes per instruction)
+                        float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * py_) * W2 + 2 * px_;
+                        *reinterpret_cast<f32x4*>(o) = (f32x4){acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]};
+                        *reinterpret_cast<f32x4*>(o + 4) = (f32x4){acc[i][2][0], acc[i][2][1], acc[i][3][0], acc[i][3][1]};
+                        *reinterpret_cast<f32x4*>(o + W2) = (f32x4){acc[i][0][2], acc[i][0][3], acc[i][1][2], acc[i][1][3]};
+                        *reinterpret_cast<f32x4*>(o + W2 + 4) = (f32x4){acc[i][2][2], acc[i][2][3], acc[i][3][2], acc[i][3][3]};
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int y = row4 ? py_ : (pxb + j) / p.Wout, xx = row4 ? px_ + j : (pxb + j) - y * p.Wout;
-                        const f32x4 v = acc[i][j];
-                        float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * y) * W2 + 2 * xx;
-                        *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
-                        *reinterpret_cast<float2*>(o + W2) = make_float2(v[2], v[3]);
+                        for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+                            for (int r = 0; r < 4; ++r) { ssum[i][0] += acc[i][j][r]; ssq[i][0] += acc[i][j][r] * acc[i][j][r]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int y = (pxb + j) / p.Wout, xx = (pxb + j) - y * p.Wout;
+                            const f32x4 v = acc[i][j];
+                            float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * y) * W2 + 2 * xx;
+                            *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+                            *reinterpret_cast<float2*>(o + W2) = make_float2(v[2], v[3]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { ssum[i][0] += v[r]; ssq[i][0] += v[r] * v[r]; }
+                        }
                     }
                 } else if (EPI == EPI_UP4) {
                     const int co = row0 >> 4, dy = (row0 >> 2) & 3;
