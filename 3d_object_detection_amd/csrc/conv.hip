@@ -2170,7 +2170,7 @@ void tune_cache_save()
 // Measure every admissible tiling of one layer on the device (1 warm-up + 3 timed launches with
 // hipEvents) and keep the fastest.  Weights are really packed for each candidate, the prologue /
 // statistics epilogue run as in production.
-constexpr int TUNE_FRAMES = 16;         // frames per timed launch of the tuner (= the default production batch)
+constexpr int TUNE_FRAMES = 16;         // frames per timed launch of the tuner (half the default bench pass of 32; the picks do not change beyond 16)
 constexpr size_t TUNE_OUT_FS = 0, TUNE_IN_FS = 0; // 0: natural per-frame strides
 
 int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose)

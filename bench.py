@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight per GPU: independent frames run on separate HIP streams (one pp_ctx each) so one "
                          "frame's kernel tails / small kernels overlap another frame's MFMA work")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=32,
                     help="independent frames per pass on one stream (pp_infer_batch: frame = grid.z of the conv launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
