@@ -81,6 +81,11 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C 3d_object_detection_amd/csrc)")
+        # torch first: its wheel bundles the HIP runtime as lib/libamdhip64.so (SONAME libamdhip64.so.7), which then also
+        # satisfies libpp_hip.so's NEEDED libamdhip64.so.7 -- ONE runtime per process.  Loaded the other way round,
+        # libpp_hip.so pulls /opt/rocm's copy, torch still loads its own (its NEEDED entry is the unversioned file name),
+        # and with two HIP runtimes in the process the first HIP call fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(os.environ.get("PP_HIP_LIB", LIB_PATH))  # PP_HIP_LIB: developer override (diagnostic builds)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the .so is stale: loud by design
