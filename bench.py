@@ -183,8 +183,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # PP_BENCH_BACKEND=gloo: rehearsal of the N-rank flow on a box with fewer GPUs than ranks (ranks share devices,
+        # the gather goes through the host) -- RCCL refuses two ranks on one device.  Never a valid measurement.
+        backend = os.environ.get("PP_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -279,6 +287,8 @@ def main():
             out["roofline"]["algorithm"] = "Winograd F(2x2,3x3): executed MFMA flops = algorithmic x 4/9"
             out["roofline"]["executed"] = round(ach * 4.0 / 9.0, 3)
             out["roofline"]["executed_frac"] = round(ach * 4.0 / 9.0 / F32_MFMA_PEAK_TFLOPS, 4)
+        if world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl":
+            out["rehearsal"] = "ranks share devices, gather over " + os.environ["PP_BENCH_BACKEND"] + ": not a measurement"
         if world == 1 and not args.no_extras:
             out["extras"] = extras(eng, clouds, dev, NB, rows)
         if world == 1 and not args.no_cpu_baseline:
