@@ -53,6 +53,7 @@ PROTOTYPES = {
     "pp_postprocess": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int, c_p]),
     "pp_infer_frame": (ctypes.c_int, [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
     "pp_infer_batch": (ctypes.c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i32), ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_fetch_frame_tensor": (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_int, c_p, c_p]),
     "pp_box_decode": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p]),
     "pp_corners2d": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p]),
     "pp_standup2d": (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
@@ -67,6 +68,12 @@ PROTOTYPES = {
     "pp_profile_begin": (ctypes.c_int, [c_p]),
     "pp_profile_end": (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
     "pp_dominant_kernel": (ctypes.c_char_p, [c_p]),
+    "pp_dominant_executed_ratio": (ctypes.c_double, [c_p]),
+    "pp_stage_profile_begin": (ctypes.c_int, [c_p]),
+    "pp_stage_profile_end": (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_double)]),
+    "pp_layer_tilings": (ctypes.c_int, [c_p, ctypes.c_char_p, ctypes.c_int]),
+    "pp_tune_export": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "pp_tune_import": (ctypes.c_int, [ctypes.c_char_p]),
     "pp_version": (ctypes.c_int, []),
 }
 

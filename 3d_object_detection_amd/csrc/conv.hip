@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include "pp_common.h"
 
 namespace {
@@ -2157,13 +2158,32 @@ std::map<std::string, std::string>& tune_cache()
     return c;
 }
 
+// Merge with what other processes wrote meanwhile, write to a temp file, rename() over the target: concurrent ranks can
+// neither tear the file nor drop each other's entries (the last rename wins with a superset of what it read).
 void tune_cache_save()
 {
     const char* path = getenv("PP_TUNE_CACHE");
     if (!path) return;
-    if (FILE* f = fopen(path, "w")) {
-        for (auto& kv : tune_cache()) fprintf(f, "%s\t%s\n", kv.first.c_str(), kv.second.c_str());
+    std::map<std::string, std::string> merged;
+    if (FILE* f = fopen(path, "r")) {
+        char line[512];
+        while (fgets(line, sizeof(line), f)) {
+            char* tab = strchr(line, '\t');
+            if (!tab) continue;
+            *tab = 0;
+            char* val = tab + 1;
+            val[strcspn(val, "\r\n")] = 0;
+            merged[line] = val;
+        }
         fclose(f);
+    }
+    for (auto& kv : tune_cache()) merged[kv.first] = kv.second;
+    char tmp[1024];
+    snprintf(tmp, sizeof(tmp), "%s.tmp.%d", path, (int)getpid());
+    if (FILE* f = fopen(tmp, "w")) {
+        for (auto& kv : merged) fprintf(f, "%s\t%s\n", kv.first.c_str(), kv.second.c_str());
+        fclose(f);
+        if (rename(tmp, path) != 0) remove(tmp);
     }
 }
 
@@ -2177,10 +2197,12 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
 {
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
-    snprintf(sig, sizeof(sig), "d%d k%d s%d u%d c%d r%d %dx%d n%d b%d", ctx->device, L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout, ctx->cfg.norm_kind,
-             ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
     std::vector<Variant> menu;
     layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0);
+    // the key carries the library version and the menu size (an entry of another build's menu is not trusted), not the
+    // device index: the GPUs of a node are identical, and ranks must be able to share rank 0's table
+    snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
+             ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
@@ -2524,8 +2546,10 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream
         if ((rc = launch_conv(ctx, net->layers[li++], x, Hin, Win, Bf[0], nullptr, raw, stat_slot(ctx, site_block(b, 0)), c, h, w, stream,
                               nullptr, nullptr, nb, 0, 0, b == 0 ? pmap : nullptr, b == 0 ? feat : nullptr))) return rc;
         // y = relu(norm(Bf[0])) -> Bf[1] + stats(site 1) (the first Resnet2 unit's leading norm)
+        if ((rc = pp_stage_mark(ctx, stream, PP_ST_NORM))) return rc;
         if ((rc = launch_norm_relu(ctx, Bf[0], Bf[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
                                    stat_slot(ctx, site_block(b, 1)), stream, nb))) return rc;
+        if ((rc = pp_stage_mark(ctx, stream, PP_ST_CONV))) return rc;
         float* cur = Bf[1];
         float* spare[3] = {Bf[0], Bf[2], Bf[3]};
         const int nunits = (b == 0) ? 2 : 3;
@@ -2601,6 +2625,39 @@ extern "C" int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box
     return pp_head_impl(ctx, rpn_out, raw, cls, box, dir, 1, stream);
 }
 
+// Test / inspection hook: copy one tensor of frame `frame` of the LAST pp_infer_batch / pp_infer_frame pass out of the
+// context's internal frame buffers (device -> device, on `stream`).  kind: 0 cls f32[A], 1 box f32[A,7], 2 dir f32[A,2],
+// 3 anchor mask u8[A], 4 rpn output f32[320,H,W] = relu(norm(concat)) as RPN.forward returns it
+// (pointpillars8_shared.py:173-181; materialised here, the fused path never stores it), 5 PFN rows f32[max_voxels,64],
+// 6 coors i32[max_voxels,3], 7 pillar count i32[1].
+extern "C" int pp_fetch_frame_tensor(pp_ctx* ctx, int frame, int kind, void* dst, void* stream_)
+{
+    if (!ctx || !dst) return pp_fail(ctx, PP_E_ARG, "pp_fetch_frame_tensor: null pointer");
+    if (frame < 0 || frame >= ctx->max_batch) return pp_fail(ctx, PP_E_ARG, "pp_fetch_frame_tensor: frame out of range");
+    hipStream_t stream = (hipStream_t)stream_;
+    pp_net* net = (pp_net*)ctx->net;
+    const size_t A = (size_t)ctx->A, mv = (size_t)ctx->cfg.max_voxels, HW = (size_t)ctx->H * ctx->W;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (kind) {
+    case 0: src = ctx->f_cls + frame * A; bytes = A * 4; break;
+    case 1: src = ctx->f_box + frame * A * 7; bytes = A * 28; break;
+    case 2: src = ctx->f_dir + frame * A * 2; bytes = A * 8; break;
+    case 3: src = ctx->f_mask + frame * A; bytes = A; break;
+    case 4: {
+        NormRef pre = norm_ref(ctx, 7, 320, 0, HW);
+        if (pre.mode == PRE_STATS) pre.acc += (size_t)frame * STAT_FS;
+        return launch_norm_relu(ctx, net->up + (size_t)frame * 320 * HW, (float*)dst, 320, (int)HW, pre, nullptr, stream);
+    }
+    case 5: src = ctx->f_feat + frame * mv * 64; bytes = mv * 64 * 4; break;
+    case 6: src = ctx->f_coors + frame * mv * 3; bytes = mv * 12; break;
+    case 7: src = ctx->f_num + frame * 4; bytes = 4; break;
+    default: return pp_fail(ctx, PP_E_ARG, "pp_fetch_frame_tensor: unknown kind");
+    }
+    PP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
 extern "C" int pp_profile_begin(pp_ctx* ctx)
 {
     if (!ctx) return PP_E_ARG;
@@ -2635,6 +2692,71 @@ extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
     for (const Layer& L : net->layers)
         if (L.kind == 0 && L.level == 0 && L.stride == 1) return L.var.name;
     return "";
+}
+
+// Executed MFMA flops / algorithmic (direct-convolution) flops of the dominant layer's tiling: Winograd F(2x2,3x3)
+// issues 16 multiplications per 2x2 output tile where the direct form needs 36.
+extern "C" double pp_dominant_executed_ratio(pp_ctx* ctx)
+{
+    if (!ctx || !ctx->net) return 1.0;
+    pp_net* net = (pp_net*)ctx->net;
+    for (const Layer& L : net->layers)
+        if (L.kind == 0 && L.level == 0 && L.stride == 1) return (L.var.wino == 1 || L.var.wino == 2 || L.var.wino == 4) ? 4.0 / 9.0 : 1.0;
+    return 1.0;
+}
+
+// The network's launch plan as text, one line per conv / deconv / head layer in execution order:
+//   "<index> kind=<0 conv3x3|1 deconv|2 head> cin=<> cout=<> stride=<> up=<> level=<> wino=<0|1|2|3> tiling=<name>"
+// (bench.py derives the executed MFMA flops of a frame from it and records it in its JSON line).
+extern "C" int pp_layer_tilings(pp_ctx* ctx, char* buf, int cap)
+{
+    if (!ctx || !ctx->net) return 0;
+    pp_net* net = (pp_net*)ctx->net;
+    std::string t;
+    char line[256];
+    int i = 0;
+    for (const Layer& L : net->layers) {
+        snprintf(line, sizeof(line), "%d kind=%d cin=%d cout=%d stride=%d up=%d level=%d wino=%d tiling=%s\n", i++, L.kind, L.cin, L.cout, L.stride, L.up, L.level,
+                 L.var.wino, L.var.name);
+        t += line;
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int)t.size();
+}
+
+// The tuner's table (layer signature -> tiling name) as text, one "signature<TAB>tiling" line each: rank 0 of a
+// multi-GPU job tunes, exports and broadcasts it, the other ranks import it before they create their context, so
+// every rank runs identical kernels.  pp_tune_export returns the length needed (excluding the NUL).
+extern "C" int pp_tune_export(char* buf, int cap)
+{
+    std::string t;
+    for (auto& kv : tune_cache()) t += kv.first + "\t" + kv.second + "\n";
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int)t.size();
+}
+
+extern "C" int pp_tune_import(const char* text)
+{
+    if (!text) return PP_E_ARG;
+    int n = 0;
+    const char* p = text;
+    while (*p) {
+        const char* e = strchr(p, '\n');
+        const size_t len = e ? (size_t)(e - p) : strlen(p);
+        std::string line(p, len);
+        const size_t tab = line.find('\t');
+        if (tab != std::string::npos && tab > 0 && tab + 1 < line.size()) { tune_cache()[line.substr(0, tab)] = line.substr(tab + 1); ++n; }
+        p += len + (e ? 1 : 0);
+    }
+    return n;
 }
 
 #if PP_WINO_STAMP

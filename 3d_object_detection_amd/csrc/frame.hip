@@ -35,17 +35,23 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
             pp_in_group in;
             memset(&in, 0, sizeof(in));
             for (int i = 0; i < g; ++i) { in.pts[i] = pts_h[b0 + i]; in.n[i] = n_h[b0 + i]; }
+            if ((rc = pp_stage_mark(ctx, stream, PP_ST_VOXELIZE))) return rc;
             if ((rc = pp_voxelize_group(ctx, b0, g, in, stream))) return rc;
+            if ((rc = pp_stage_mark(ctx, stream, PP_ST_MASK))) return rc;
             if ((rc = pp_anchor_mask_group(ctx, b0, g, stream))) return rc;
+            if ((rc = pp_stage_mark(ctx, stream, PP_ST_PFN))) return rc;
             if ((rc = pp_pfn_pmap_group(ctx, b0, g, stream))) return rc;
         }
+        if ((rc = pp_stage_mark(ctx, stream, PP_ST_CONV))) return rc;
         if ((rc = pp_run_backbone(ctx, nullptr, nb, stream, ctx->f_pmap, ctx->f_feat))) return rc;
+        if ((rc = pp_stage_mark(ctx, stream, PP_ST_HEAD))) return rc;
         if ((rc = pp_run_head_fused(ctx, ctx->f_cls, ctx->f_box, ctx->f_dir, nb, stream))) return rc;
+        if ((rc = pp_stage_mark(ctx, stream, PP_ST_POST))) return rc;
         for (int b0 = 0; b0 < nb; b0 += PP_GROUP) {
             const int g = nb - b0 < PP_GROUP ? nb - b0 : PP_GROUP;
             if ((rc = pp_postprocess_group(ctx, b0, g, det, det_count, nms_mode, stream))) return rc;
         }
-        return 0;
+        return pp_stage_mark(ctx, stream, -1);
     }
     // frames are dealt round-robin to (1 + naux) streams: the caller's and naux internal ones.  The GPU exposes
     // 4 hardware queues by default, so more than 3 internal streams only adds queue-switch overhead.

@@ -22,7 +22,47 @@ int pp_fail(pp_ctx* ctx, int code, const char* msg)
 }
 
 extern "C" const char* pp_last_error(pp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-extern "C" int pp_version(void) { return 1; }
+extern "C" int pp_version(void) { return 2; }
+
+int pp_stage_mark(pp_ctx* ctx, hipStream_t stream, int id)
+{
+    if (!ctx->stage_on) return 0;
+    if (ctx->stage_used >= ctx->stage_ev.size()) {
+        hipEvent_t e;
+        PP_HIP(hipEventCreate(&e));
+        ctx->stage_ev.push_back(e);
+        ctx->stage_id.push_back(-1);
+    }
+    PP_HIP(hipEventRecord(ctx->stage_ev[ctx->stage_used], stream));
+    ctx->stage_id[ctx->stage_used] = id;
+    ctx->stage_used++;
+    return 0;
+}
+
+extern "C" int pp_stage_profile_begin(pp_ctx* ctx)
+{
+    if (!ctx) return PP_E_ARG;
+    ctx->stage_on = true;
+    ctx->stage_used = 0;
+    return 0;
+}
+
+extern "C" int pp_stage_profile_end(pp_ctx* ctx, double* ms_h)
+{
+    if (!ctx || !ms_h) return PP_E_ARG;
+    ctx->stage_on = false;
+    for (int i = 0; i < PP_ST_COUNT; ++i) ms_h[i] = 0.0;
+    for (size_t i = 0; i + 1 < ctx->stage_used; ++i) {
+        const int id = ctx->stage_id[i];
+        if (id < 0 || id >= PP_ST_COUNT) continue;
+        PP_HIP(hipEventSynchronize(ctx->stage_ev[i + 1]));
+        float ms = 0.f;
+        PP_HIP(hipEventElapsedTime(&ms, ctx->stage_ev[i], ctx->stage_ev[i + 1]));
+        ms_h[id] += ms;
+    }
+    ctx->stage_used = 0;
+    return 0;
+}
 
 template <typename T>
 static hipError_t dalloc(T** p, size_t count)
@@ -171,6 +211,7 @@ extern "C" void pp_destroy(pp_ctx* ctx)
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->stage_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 

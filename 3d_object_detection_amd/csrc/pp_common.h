@@ -103,7 +103,15 @@ struct pp_ctx {
     std::vector<hipEvent_t> prof_ev; // start/stop pairs
     size_t prof_used = 0;
     double prof_flops = 0.0;
+    // ---- per-stage timing (pp_stage_profile_begin/end): one event per stage boundary on the caller's stream ----
+    bool stage_on = false;
+    std::vector<hipEvent_t> stage_ev;
+    std::vector<int> stage_id; // stage that FOLLOWS event i (-1: end of the pass)
+    size_t stage_used = 0;
 };
+// stage ids of pp_stage_mark / pp_stage_profile_end
+enum { PP_ST_VOXELIZE = 0, PP_ST_MASK = 1, PP_ST_PFN = 2, PP_ST_CONV = 3, PP_ST_NORM = 4, PP_ST_HEAD = 5, PP_ST_POST = 6, PP_ST_COUNT = 8 };
+int pp_stage_mark(pp_ctx* ctx, hipStream_t stream, int id); // no-op unless stage profiling is on
 
 int pp_fail_hip(pp_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
 int pp_fail(pp_ctx* ctx, int code, const char* msg);

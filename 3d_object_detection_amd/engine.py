@@ -148,6 +148,7 @@ class Engine:
         self.max_batch = c.max_batch
         self.cfg = c
         self.max_points = c.max_points
+        self.cnt_stride = 1 + _lib.PP_MAX_CLASSES  # int32 per frame in det_count (PP_DET_COUNT_STRIDE)
         self.norm = norm
         with torch.cuda.device(self.device):
             self.ctx = self.lib.pp_create(device_index, ctypes.byref(c))
@@ -268,8 +269,46 @@ class Engine:
                        self.ctx, "pp_infer_batch")
         return det, cnt
 
+    def fetch(self, frame, what):
+        """Inspection hook (pp_fetch_frame_tensor): one tensor of frame `frame` of the last infer_batch / infer_frame
+        pass, copied out of the context's internal buffers.  what: cls | box | dir | mask | rpn | feat | coors | num."""
+        kinds = {"cls": (0, (self.A,), torch.float32), "box": (1, (self.A, 7), torch.float32), "dir": (2, (self.A, 2), torch.float32),
+                 "mask": (3, (self.A,), torch.uint8), "rpn": (4, (320, self.H, self.W), torch.float32),
+                 "feat": (5, (self.max_voxels, 64), torch.float32), "coors": (6, (self.max_voxels, 3), torch.int32),
+                 "num": (7, (1,), torch.int32)}
+        kind, shape, dtype = kinds[what]
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_fetch_frame_tensor(self.ctx, int(frame), kind, _ptr(out), _stream()), self.ctx, "pp_fetch_frame_tensor")
+        return out
+
     def dominant_kernel(self):
         return self.lib.pp_dominant_kernel(self.ctx).decode()
+
+    def executed_ratio(self):
+        return float(self.lib.pp_dominant_executed_ratio(self.ctx))
+
+    def layer_tilings(self):
+        """[{kind, cin, cout, stride, up, level, wino, tiling}] in execution order (pp_layer_tilings)."""
+        n = self.lib.pp_layer_tilings(self.ctx, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self.lib.pp_layer_tilings(self.ctx, buf, n + 1)
+        out = []
+        for line in buf.value.decode().splitlines():
+            head, tiling = line.split(" tiling=")
+            d = {k: int(v) for k, v in (kv.split("=") for kv in head.split()[1:])}
+            d["tiling"] = tiling
+            out.append(d)
+        return out
+
+    def stage_profile_begin(self):
+        _lib.check(self.lib.pp_stage_profile_begin(self.ctx), self.ctx, "pp_stage_profile_begin")
+
+    def stage_profile_end(self):
+        ms = (ctypes.c_double * 8)()
+        _lib.check(self.lib.pp_stage_profile_end(self.ctx, ms), self.ctx, "pp_stage_profile_end")
+        names = ["voxelize", "anchor_mask", "pfn_pmap", "conv", "norm_relu_stats", "head", "postprocess"]
+        return {n: ms[i] for i, n in enumerate(names)}
 
     def profile_begin(self):
         _lib.check(self.lib.pp_profile_begin(self.ctx), self.ctx, "pp_profile_begin")
@@ -278,6 +317,11 @@ class Engine:
         ms, n, fl = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
         _lib.check(self.lib.pp_profile_end(self.ctx, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.ctx, "pp_profile_end")
         return ms.value, n.value, fl.value
+
+
+def tuning_lib():
+    """The loaded C library (pp_tune_export / pp_tune_import are process-wide, not per context)."""
+    return _lib.load()
 
 
 def engine_for(config, norm=None):

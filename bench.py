@@ -6,14 +6,24 @@
 
 A step = one pass of `--batch` independent frames per GPU through pp_infer_batch (each frame keeps the
 reference's batch=1 semantics, train.py:219-242: no statistic is shared between frames; the frames only share
-kernel launches) plus the async D2H of their detection records.  Workload: configs/eight_20cm.json, synthetic KITTI-shape
-20k-point clouds already resident in HBM, random-init weights of the reference architecture.
-Frames are sharded by index across ranks (weak scaling: `--batch` frames per rank per step, no data-path
-collective); RCCL only gathers the detection records once at the end of the timed region.
-Rank 0 prints ONE JSON line with `roofline` (dominant conv kernel timed with HIP events on its launch
-stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle on the host cores).
+kernel launches) plus the async D2H of their detection records.  Workload: configs/<config>.json, synthetic
+LiDAR-shaped clouds, random-init weights of the reference architecture.
+
+Two timed regions of K steps each, both bracketed by barrier + synchronize, max over ranks:
+  * `value`            -- clouds already resident in HBM when the region starts (the contract's definition of `value`);
+  * `value_host_start` -- SURVEY 8(d)'s timer, the one train.py:223-237 uses: clouds start in pinned HOST memory, their
+                          H2D copies run inside the region (copy stream, double-buffered, overlapping the previous pass),
+                          the region ends when the last detection record is on the host.
+Frames are sharded by index across ranks with no data-path collective; RCCL only gathers the detection records once
+at the end of a region (one all_gather).  Default: weak scaling, `--batch` frames per rank per step.
+`--global-batch G` (BASELINE config 5: G = 64) fixes the TOTAL frames per step and shards them, strong scaling.
+Rank 0 prints ONE JSON line with `roofline` (dominant conv kernel timed with HIP events on its launch stream inside
+the resident region; `frac` = EXECUTED MFMA flops / fp32-MFMA peak; per-stage HBM rooflines under `stages`) and, at
+N=1, `cpu_baseline` (the CPU oracle on the host cores) and `extras` (batch-1 latency, trained-like head bias).
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -27,23 +37,34 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+CLOUD_DESC = {"eight_20cm": "KITTI-shape 64-beam 20k-point", "ntusl_10cm": "64-beam two-sweep 60k-point", "nuscene": "nuScenes-shape 32-beam 34k-point"}
+
+
+def source_hash():
+    """sha256 over the HIP sources the library was built from: ties a committed PMC figure to the build it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "3d_object_detection_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "3d_object_detection_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def hbm_traffic(tiling, frames):
-    """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside this process, so the
-    figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    (profiles/r01_hbm_traffic.json, made by tools/profile_round.sh + tools/hbm_traffic.py; FETCH_SIZE doubled per the
-    gfx950 correction of MI355X_MICROARCH.md) -- and only if they were taken for the tiling and batch that ran."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        e = t["tilings"].get(tiling)
-        if e is None or t["frames_per_launch"] != frames:
-            return None, None
-        return int(e["hbm_bytes_per_launch"]), "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+    """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside this process, so the figure
+    comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh +
+    tools/hbm_traffic.py; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -- and only if they were
+    taken for the tiling, the batch AND the source tree that is running; otherwise null."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            e = t["tilings"].get(tiling)
+            if e is None or t["frames_per_launch"] != frames or t.get("source_hash") != source_hash():
+                continue
+            return int(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def host_cores():
@@ -71,26 +92,26 @@ def host_cores():
     return min(n, int(os.environ.get("PP_CPU_THREADS", "16")))
 
 
-def cpu_baseline(synth, n_frames=8):
+def cpu_baseline(synth, config, n_frames=8):
     """The CPU oracle (oracle/: C for voxelise/mask/NMS, torch-CPU fp32 for PFN/backbone/head) on the
     host cores, bounded sample (1 warm + n_frames timed frames of the same workload)."""
     from oracle import c_oracle as C
     from oracle import pp_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    cfg = synth.load_config("eight_20cm")
+    cfg = synth.load_config(config)
     s = O.voxel_setup(cfg)
     a = O.make_anchors(s)
     sd = synth.seeded_state_dict(0)
     C.lib()
-    clouds = [synth.lidar_cloud("eight_20cm", seed=1000 + i) for i in range(n_frames + 1)]
+    clouds = [synth.lidar_cloud(config, seed=1000 + i) for i in range(n_frames + 1)]
 
     def frame(pts):
         v, c, n = C.points_to_voxels(pts, s["voxel_size"], s["offset"], s["grid_size"], cfg["max_voxels"], cfg["max_num_points"])
         mask = C.create_mask(c, s["grid_size"], a["anchors_coors"])
         rpn = O.backbone(O.scatter(O.pfn(v, n, c, sd, s), c, s["grid_size"]), sd)
         cls, box, dr = O.head(rpn, sd)
-        return O.postprocess(cls, box, dr, mask, a["anchors"], a["class_masks"], cfg["center_limit"])
+        return O.postprocess(cls, box, dr, mask, a["anchors"], a["class_masks"], cfg["center_limit"], nms_fn=C.nms_aabb)
 
     frame(clouds[0])
     t0 = time.time()
@@ -98,64 +119,70 @@ def cpu_baseline(synth, n_frames=8):
         frame(p)
     dt = time.time() - t0
     return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} frames of eight_20cm (20k-pt clouds, batch=1) after 1 warm-up, oracle/ CPU path, {dt:.1f} s"}
+            "sample": f"{n_frames} frames of {config} ({clouds[0].shape[0]}-pt clouds, batch=1) after 1 warm-up, oracle/ CPU path, {dt:.1f} s"}
 
 
-def extras(eng, clouds, dev, NB, rows):
-    """Untimed side measurements for the report (rank 0, N=1, after the timed region):
-    * the PCIe-inclusive rate: the same pass with the clouds in pinned HOST memory, their H2D copies enqueued ahead
-      of pp_infer_batch on the same stream (SURVEY 8(d)'s timer; never `value`);
-    * single-frame latency of the stand-alone stage entry points in the reference's buckets (train.py:224-236):
-      pre = voxelise + anchor mask, net = PFN + scatter + backbone + head, post = post-processing."""
+def frame_flops(H, W, tilings):
+    """Algorithmic (direct-convolution) and executed MFMA flops of one frame from the launch plan (SURVEY 8(d) formula:
+    203.2 GFLOP at eight_20cm).  A Winograd F(2x2,3x3) layer executes 4/9 of its algorithmic multiplications."""
+    alg = ex = 0.0
+    for L in tilings:
+        hw = (H >> L["level"]) * (W >> L["level"])
+        if L["kind"] == 0:
+            f = 2.0 * hw * L["cin"] * L["cout"] * 9
+        elif L["kind"] == 1:
+            f = 2.0 * hw * L["cin"] * L["cout"] * L["up"] * L["up"]
+        else:
+            f = 2.0 * hw * L["cin"] * L["cout"]
+        alg += f
+        ex += f * (4.0 / 9.0 if L["wino"] in (1, 2, 4) else 1.0)
+    return alg, ex
+
+
+def stage_rooflines(eng, clouds, NB, cfg, passes=3):
+    """Untimed side pass with one HIP event per stage boundary (pp_stage_profile_*): GPU ms per stage and frame, against
+    the algorithmic HBM bytes of SURVEY 8(d) (fp32) and the 8 TB/s peak; conv / head stages against the MFMA peak."""
+    eng.infer_batch(clouds[:NB])
+    torch.cuda.synchronize()
+    P = float(np.mean([int(eng.fetch(b, "num").item()) for b in range(NB)]))
+    N = float(np.mean([c.shape[0] for c in clouds[:NB]]))
+    eng.stage_profile_begin()
+    for _ in range(passes):
+        eng.infer_batch(clouds[:NB])
+    torch.cuda.synchronize()
+    ms = eng.stage_profile_end()
+    per_frame = {k: v / (passes * NB) for k, v in ms.items()}
+    T = int(cfg["max_num_points"])
+    gx, gy = int(eng.grid_size[0]), int(eng.grid_size[1])
+    HW = eng.H * eng.W
+    bytes_ = {
+        "voxelize": 16 * N + P * (16 * T + 16),                       # points read + pillars (voxels, coors, count) written
+        "anchor_mask": 3 * 4 * gx * gy + eng.A,                        # occupancy table written + two scan passes, mask written
+        "pfn_pmap": P * 16 * T + 256 * P + 4 * gx * gy,                # pillars read, PFN rows + pillar map written
+        "norm_relu_stats": 2 * 4 * HW * (64 + 128 / 4 + 256 / 16),     # block-head maps read + written once, 3 levels
+        "postprocess": 4 * eng.A + eng.A + 3 * 1000 * (28 + 8 + 28),   # cls logits + mask read, box/dir/anchor rows of <= 1000 candidates per class
+    }
     out = {}
-    host = [c.cpu().pin_memory() for c in clouds]
-    stage = [[torch.empty_like(c) for c in clouds[:1] * NB] for _ in range(2)]
-    for b in range(NB):
-        for k in range(2):
-            stage[k][b] = torch.empty_like(clouds[b % len(clouds)])
-    det = torch.zeros((NB, rows, 9), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((NB, 1 + 8), dtype=torch.int32, device=dev)
-    det_h = torch.zeros((NB, rows, 9), dtype=torch.float32).pin_memory()
-    cnt_h = torch.zeros((NB, 1 + 8), dtype=torch.int32).pin_memory()
-
-    def hstep(i):
-        bufs = stage[i & 1]
-        for b in range(NB):
-            bufs[b].copy_(host[b % len(host)], non_blocking=True)
-        eng.infer_batch(bufs, det, cnt)
-        det_h.copy_(det, non_blocking=True)
-        cnt_h.copy_(cnt, non_blocking=True)
-
-    for i in range(2):
-        hstep(i)
-    torch.cuda.synchronize()
-    n = 10
-    t0 = time.perf_counter()
-    for i in range(n):
-        hstep(i)
-    torch.cuda.synchronize()
-    out["value_with_h2d"] = round(n * NB / (time.perf_counter() - t0), 3)
-
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    acc = [0.0, 0.0, 0.0]
-    reps = 5
-    for r in range(reps + 1):
-        pts = clouds[r % len(clouds)]
-        ev[0].record()
-        vox, coors, npts, num = eng.voxelize(pts)
-        mask = eng.anchor_mask(coors, num)
-        ev[1].record()
-        cls, box, dr = eng.head(eng.backbone(eng.scatter(eng.pfn(vox, coors, npts, num), coors, num)))
-        ev[2].record()
-        eng.postprocess(cls, box, dr, mask)
-        ev[3].record()
-        torch.cuda.synchronize()
-        if r:  # first repetition warms up
-            for k in range(3):
-                acc[k] += ev[k].elapsed_time(ev[k + 1])
-    out["stage_ms_single_frame"] = {"pre": round(acc[0] / reps, 4), "net": round(acc[1] / reps, 4), "post": round(acc[2] / reps, 4),
-                                    "note": "stand-alone stage entry points, one frame, dense canvas (the fused batched path shares launches across frames)"}
-    return out
+    for k, b in bytes_.items():
+        t = per_frame[k] * 1e-3
+        gbs = b / t / 1e9 if t > 0 else 0.0
+        out[k] = {"bound": "hbm", "ms_per_frame": round(per_frame[k], 5), "algorithmic_bytes_per_frame": int(b), "achieved": round(gbs, 2),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}
+    til = eng.layer_tilings()
+    alg, ex = frame_flops(eng.H, eng.W, til)
+    head = [L for L in til if L["kind"] == 2]
+    alg_h, _ = frame_flops(eng.H, eng.W, head)
+    for k, (a_, e_) in {"conv": (alg - alg_h, ex - alg_h), "head": (alg_h, alg_h)}.items():
+        t = per_frame[k] * 1e-3
+        out[k] = {"bound": "mfma", "ms_per_frame": round(per_frame[k], 5), "algorithmic_flops_per_frame": a_, "executed_flops_per_frame": e_,
+                  "achieved": round(e_ / t / 1e12, 2) if t > 0 else 0.0, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(e_ / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if t > 0 else 0.0}
+    total = sum(per_frame.values())
+    whole = {"gpu_ms_per_frame": round(total, 5), "algorithmic_gflop": round(alg / 1e9, 2), "executed_gflop": round(ex / 1e9, 2),
+             "executed_tflops": round(ex / (total * 1e-3) / 1e12, 2) if total > 0 else 0.0,
+             "executed_frac": round(ex / (total * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if total > 0 else 0.0,
+             "mean_points": N, "mean_pillars": P}
+    return out, whole, til
 
 
 def main():
@@ -165,19 +192,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="eight_20cm")
     ap.add_argument("--cls-bias", type=float, default=None, help="'trained-like' head bias (e.g. -4.6); default random init")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="frames in flight per GPU: independent frames run on separate HIP streams (one pp_ctx each) so one "
-                         "frame's kernel tails / small kernels overlap another frame's MFMA work")
     ap.add_argument("--batch", type=int, default=32,
-                    help="independent frames per pass on one stream (pp_infer_batch: frame = grid.z of the conv launches)")
+                    help="independent frames per pass per GPU (pp_infer_batch: frame = grid.z of the conv launches); weak scaling")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="TOTAL frames per step, sharded by frame index over the ranks (strong scaling; BASELINE config 5: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (PCIe-inclusive rate, stage latencies)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (stage rooflines, batch-1 latency, trained-like bias)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PP_BENCH_ENGINE=<module>: the CPU rehearsal of the rank flow (tests/test_bench_ranks.py) swaps the engine and the
+    # device layer for a stub; never a measurement
+    stub = importlib.import_module(os.environ["PP_BENCH_ENGINE"]) if os.environ.get("PP_BENCH_ENGINE") else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -185,117 +214,209 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # PP_BENCH_BACKEND=gloo: rehearsal of the N-rank flow on a box with fewer GPUs than ranks (ranks share devices,
         # the gather goes through the host) -- RCCL refuses two ranks on one device.  Never a valid measurement.
-        backend = os.environ.get("PP_BENCH_BACKEND", "nccl")
-        if backend != "nccl":
-            local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
+        backend = "gloo" if stub else os.environ.get("PP_BENCH_BACKEND", "nccl")
+        if not stub:
+            if backend != "nccl":
+                local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    dev = stub.device() if stub else torch.device("cuda", local)
+    if not stub:
+        torch.cuda.set_device(dev)
+    D = stub if stub else importlib.import_module("3d_object_detection_amd.devlayer")
 
     synth = importlib.import_module("3d_object_detection_amd.synth")
-    eng_mod = importlib.import_module("3d_object_detection_amd.engine")
     shard = importlib.import_module("3d_object_detection_amd.shard")
+    eng_mod = stub if stub else importlib.import_module("3d_object_detection_amd.engine")
     cfg = synth.load_config(args.config)
     cfg["device"] = dev
-    S = max(1, args.streams)
-    engines, streams = [], []
-    for _ in range(S):
-        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=max(1, args.batch))
-        e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
-        engines.append(e)
-        streams.append(torch.cuda.Stream(device=dev))
-    eng = engines[0]
 
-    pool = 8
-    clouds = [torch.from_numpy(synth.lidar_cloud(args.config, seed=1000 + rank * pool + i)).to(dev) for i in range(pool)]
     K, W = args.steps, args.warmup
-    NB = max(1, args.batch)
+    if args.global_batch > 0:
+        mine = shard.frames_for_rank(rank, world, args.global_batch)  # this rank's frame indices of every step
+        scaling = "strong"
+    else:
+        mine = [rank * args.batch + b for b in range(max(1, args.batch))]
+        scaling = "weak"
+    NB = len(mine)
+    frames_per_step = args.global_batch if args.global_batch > 0 else world * NB
+    MAXB = 32  # frames per pp_infer_batch pass; a rank with more frames per step runs several passes
+    passes = [mine[i:i + MAXB] for i in range(0, NB, MAXB)] if NB else []
+
+    def make_engine():
+        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=max(1, min(NB, MAXB)))
+        e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
+        return e
+
+    # rank 0 tunes (pp_commit_weights measures the tilings on the device), the others import its table first:
+    # every rank runs identical kernels
+    eng = make_engine() if rank == 0 else None
+    if dist:
+        shard.share_tuning(eng_mod.tuning_lib(), src=0)
+    if eng is None:
+        eng = make_engine()
+
+    # one distinct cloud per frame of a step (a pool smaller than the pass re-reads cache-warm inputs)
+    host = [D.pin(torch.from_numpy(synth.lidar_cloud(args.config, seed=1000 + f))) for f in mine]
+    clouds = [h.to(dev) for h in host]
+    stage_bufs = [[torch.empty_like(c) for c in clouds] for _ in range(2)]
     rows = eng.cfg.num_classes * eng.cfg.nms_post_max
-    det = torch.zeros((K, NB, rows, 9), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((K, NB, 1 + 8), dtype=torch.int32, device=dev)
-    det_h = torch.zeros((K, NB, rows, 9), dtype=torch.float32).pin_memory()
-    cnt_h = torch.zeros((K, NB, 1 + 8), dtype=torch.int32).pin_memory()
+    ncnt = eng.cnt_stride
+    det = torch.zeros((K, max(NB, 1), rows, 9), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((K, max(NB, 1), ncnt), dtype=torch.int32, device=dev)
+    det_h = D.pin(torch.zeros((K, max(NB, 1), rows, 9), dtype=torch.float32))
+    cnt_h = D.pin(torch.zeros((K, max(NB, 1), ncnt), dtype=torch.int32))
+    compute, copier = D.stream(dev), D.stream(dev)
+    h2d_done = [D.event() for _ in range(2)]
+    pass_done = [D.event() for _ in range(2)]
 
-    def step(i, j):
-        # one step = NB independent frames (batch=1 semantics per frame: no cross-frame statistics)
-        with torch.cuda.stream(streams[i % S]):
-            engines[i % S].infer_batch([clouds[(i * NB + b) % pool] for b in range(NB)], det[j], cnt[j])
-            det_h[j].copy_(det[j], non_blocking=True)
-            cnt_h[j].copy_(cnt[j], non_blocking=True)
+    def run_passes(srcs, j):
+        o = 0
+        for p in passes:
+            eng.infer_batch(srcs[o:o + len(p)], det[j, o:o + len(p)], cnt[j, o:o + len(p)])
+            o += len(p)
+        det_h[j].copy_(det[j], non_blocking=True)
+        cnt_h[j].copy_(cnt[j], non_blocking=True)
 
-    for i in range(W):
-        step(i, i % K)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for e in engines:
-        e.profile_begin()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(i, i)
-    if dist:
-        for s_ in streams:  # the one collective of the path follows the compute it gathers (the steps ran on side streams)
-            torch.cuda.current_stream(dev).wait_stream(s_)
-        shard.gather_detections(det.view(K * NB, rows, 9), cnt.view(K * NB, 1 + 8))
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = [e.profile_end() for e in engines]
-    k_n = sum(q[1] for q in prof)
-    k_ms = sum(q[0] * q[1] for q in prof) / max(k_n, 1)
-    k_flops = prof[0][2]
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def step_resident(i, j):
+        with D.use_stream(compute):
+            run_passes(clouds, j)
+
+    def step_host(i, j):
+        # H2D of step i on the copy stream (waits until the pass that last read this staging set is done),
+        # compute waits for it: the copy of step i+1 overlaps the kernels of step i
+        s = i & 1
+        with D.use_stream(copier):
+            D.wait_event(copier, pass_done[s])
+            for b in range(NB):
+                stage_bufs[s][b].copy_(host[b], non_blocking=True)
+            D.record(h2d_done[s], copier)
+        with D.use_stream(compute):
+            D.wait_event(compute, h2d_done[s])
+            run_passes(stage_bufs[s], j)
+            D.record(pass_done[s], compute)
+
+    def timed_region(step, profile):
+        for i in range(W):
+            step(i, i % K)
+        D.synchronize()
+        if dist:
+            dist.barrier()
+        D.synchronize()
+        if profile:
+            eng.profile_begin()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i, i)
+        if dist:
+            D.wait_stream(D.current_stream(dev), compute)  # the one collective of the path follows the compute it gathers
+            shard.gather_detections(det.view(K * max(NB, 1), rows, 9), cnt.view(K * max(NB, 1), ncnt))
+        D.synchronize()
+        if dist:
+            dist.barrier()
+        D.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_end() if profile else None
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof
+
+    for ev in pass_done:
+        D.record(ev, compute)
+    elapsed, prof = timed_region(step_resident, True)
+    mean_det = float(cnt_h[:, :, 0].float().mean())
+    elapsed_h, _ = timed_region(step_host, False)
 
     if rank == 0:
+        k_ms, k_n, k_flops = prof
+        ratio = eng.executed_ratio()
         out = {
-            "metric": f"point-cloud frames/sec end-to-end (voxelise→NMS), {args.config}, 1/2/4/8 MI355X",  # BASELINE.json's metric (default config eight_20cm)
-            "value": round(world * K * NB / elapsed, 3),
+            "metric": f"point-cloud frames/sec end-to-end (voxelise→NMS), {args.config}, {world}x MI355X",  # BASELINE.json's metric (default config eight_20cm)
+            "value": round(K * frames_per_step / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"configs/{args.config}.json, synthetic KITTI-shape 20k-point clouds resident in HBM, "
-                                   "independent frames (batch=1 semantics, NB per pass), random-init weights (InstanceNorm backbone), AABB NMS",
-                       "frames_per_step": world * NB, "frames_per_pass_per_gpu": NB, "parallelism": f"frame-sharded x{world}", "streams_per_gpu": S,
-                       "cls_bias": args.cls_bias, "mean_detections": float(cnt_h[:, :, 0].float().mean())},
+            "value_host_start": round(K * frames_per_step / elapsed_h, 3),
+            "ms_per_step_host_start": round(elapsed_h / K * 1e3, 4),
+            "config": {"workload": f"configs/{args.config}.json, synthetic {CLOUD_DESC.get(args.config, 'LiDAR-shaped')} clouds "
+                                   f"(mean {int(np.mean([c.shape[0] for c in clouds])) if clouds else 0} points, one distinct cloud per frame of a step), "
+                                   "independent frames (batch=1 semantics), random-init weights (InstanceNorm backbone), AABB NMS; "
+                                   "`value`: clouds resident in HBM; `value_host_start`: clouds in pinned host memory, H2D inside the timed region (SURVEY 8(d) timer)",
+                       "frames_per_step": frames_per_step, "frames_per_pass_per_gpu": min(NB, MAXB), "parallelism": f"frame-sharded x{world}",
+                       "global_batch": args.global_batch or None, "cls_bias": args.cls_bias, "mean_detections": mean_det},
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0
-        traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), NB)
-        out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{NB} frames, tiling '{eng.dominant_kernel()}'",
-                           "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_launch_ms": round(k_ms, 5), "launches": k_n, "flops_per_launch": k_flops}
-        if eng.dominant_kernel().startswith("wino"):
-            # Winograd F(2x2,3x3) issues 16 MFMA multiplications where the direct form needs 36: `achieved` prices the
-            # ALGORITHMIC (direct-conv) flops and can pass the MFMA peak; `executed` is what the matrix cores really ran
-            out["roofline"]["algorithm"] = "Winograd F(2x2,3x3): executed MFMA flops = algorithmic x 4/9"
-            out["roofline"]["executed"] = round(ach * 4.0 / 9.0, 3)
-            out["roofline"]["executed_frac"] = round(ach * 4.0 / 9.0 / F32_MFMA_PEAK_TFLOPS, 4)
-        if world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl":
-            out["rehearsal"] = "ranks share devices, gather over " + os.environ["PP_BENCH_BACKEND"] + ": not a measurement"
-        if world == 1 and not args.no_extras:
-            out["extras"] = extras(eng, clouds, dev, NB, rows)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(synth, args.cpu_frames)
+        traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), min(NB, MAXB))
+        out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{min(NB, MAXB)} frames, tiling '{eng.dominant_kernel()}'",
+                           "achieved": round(ach * ratio, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach * ratio / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                           "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                           "algorithmic_flops_per_launch": k_flops, "executed_flops_per_launch": k_flops * ratio,
+                           "algorithmic_tflops": round(ach, 3),
+                           "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
+                                   "count in `algorithmic_*`)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+        if stub or (world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl"):
+            out["rehearsal"] = "stub engine / ranks share devices, gather over gloo: not a measurement"
+        if world == 1 and not args.no_extras and not stub:
+            stages, whole, til = stage_rooflines(eng, clouds, min(NB, MAXB), cfg)
+            out["roofline"]["stages"] = stages
+            out["roofline"]["whole_frame"] = whole
+            out["extras"] = extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D)
+            out["extras"]["tilings"] = [L["tiling"] for L in til]
+        if world == 1 and not args.no_cpu_baseline and not stub:
+            out["cpu_baseline"] = cpu_baseline(synth, args.config, args.cpu_frames)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
+    """Untimed side measurements (rank 0, N=1, after the timed regions)."""
+    out = {}
+    # batch=1 latency of this build (BASELINE config 2 is quoted at batch=1): one frame per pp_infer_frame call, synchronised
+    # after every frame like train.py:236 -- resident cloud, and from pinned host memory
+    det1, cnt1 = eng.infer_frame(clouds[0])
+    torch.cuda.synchronize()
+    n = 30
+    for name, src in (("resident", clouds), ("host_start", host)):
+        t0 = time.perf_counter()
+        for i in range(n):
+            pts = src[i % len(src)]
+            if name == "host_start":
+                pts = pts.to(dev, non_blocking=True)
+            d, c = eng.infer_frame(pts, det1, cnt1)
+            c.cpu()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"batch1_latency_ms_{name}"] = round(dt / n * 1e3, 4)
+        out[f"batch1_frames_per_s_{name}"] = round(n / dt, 2)
+    # the same resident pass with a trained-like head bias (few candidates instead of ~900 detections per frame)
+    if args.cls_bias is None:
+        eng.load_state_dict(synth.seeded_state_dict(0, cls_bias=-4.6))
+        NB = min(len(clouds), eng.max_batch)
+        for _ in range(2):
+            d, c = eng.infer_batch(clouds[:NB])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            d, c = eng.infer_batch(clouds[:NB], d, c)
+        torch.cuda.synchronize()
+        out["value_trained_like_bias"] = round(10 * NB / (time.perf_counter() - t0), 3)
+        out["mean_detections_trained_like_bias"] = float(c[:, 0].float().mean())
+        eng.load_state_dict(synth.seeded_state_dict(0))
+    return out
 
 
 if __name__ == "__main__":

@@ -111,6 +111,13 @@ int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* de
 int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int32_t* n_h, int nb, float* det, int32_t* det_count,
                    int nms_mode, void* stream);
 
+/* Inspection hook for the parity tests: copies one tensor of frame `frame` of the LAST pp_infer_batch / pp_infer_frame
+ * pass out of the context's internal buffers into caller memory (device pointer, enqueued on stream).
+ * kind 0 cls f32[A] | 1 box f32[A,7] | 2 dir f32[A,2] | 3 anchor mask u8[A] | 4 rpn output f32[320,H,W] as RPN.forward
+ * returns it (pointpillars8_shared.py:173-181; the fused path never stores it, it is materialised for the copy) |
+ * 5 PFN rows f32[max_voxels,64] | 6 coors i32[max_voxels,3] | 7 pillar count i32[1]. */
+int pp_fetch_frame_tensor(pp_ctx* ctx, int frame, int kind, void* dst, void* stream);
+
 /* Stateless box ops (replace framework/box_torch_ops.py:18-77 and framework/nms.py:6-40,
  * eval/iou.py:438-473). */
 int pp_box_decode(const float* enc, const float* anchors, float* out, int64_t n, void* stream);
@@ -154,6 +161,23 @@ int pp_eval_fused_statistics(const double* overlaps, int64_t ov_ld, double* pr, 
  * the number of launches seen and the algorithmic FLOPs of one launch (2*H*W*Cin*Cout*9). */
 int pp_profile_begin(pp_ctx* ctx);
 int pp_profile_end(pp_ctx* ctx, double* avg_ms_h, int32_t* launches_h, double* flops_per_launch_h);
+/* executed MFMA flops / algorithmic (direct-convolution) flops of that layer's tiling (Winograd F(2x2,3x3): 4/9) */
+double pp_dominant_executed_ratio(pp_ctx* ctx);
+/* Per-stage GPU time of the fused path: between begin and end every pp_infer_batch pass records one event per stage
+ * boundary on its stream; end synchronises and sums the milliseconds per stage into ms_h[8]:
+ * 0 voxelise, 1 anchor mask, 2 PFN + pillar map, 3 conv / deconv launches (+ statistics finalisation),
+ * 4 norm_relu_stats, 5 head, 6 post-processing (7 unused).  Meant for an untimed side pass of bench.py. */
+int pp_stage_profile_begin(pp_ctx* ctx);
+int pp_stage_profile_end(pp_ctx* ctx, double* ms_h);
+/* The network's launch plan as text, one line per conv / deconv / head layer in execution order:
+ * "<index> kind=<0 conv3x3|1 deconv|2 head> cin= cout= stride= up= level= wino=<0 direct|1,2,4 Winograd|3 1x1 GEMM> tiling=<name>".
+ * Returns the text length (buf may be NULL to query). */
+int pp_layer_tilings(pp_ctx* ctx, char* buf_h, int cap);
+/* The autotuner's table (process-wide) as text, "layer signature<TAB>tiling" per line.  Rank 0 of a multi-GPU job
+ * tunes, exports and broadcasts it; the other ranks import it BEFORE pp_commit_weights so all ranks run identical
+ * kernels.  pp_tune_export returns the text length (buf may be NULL to query), pp_tune_import the lines taken. */
+int pp_tune_export(char* buf_h, int cap);
+int pp_tune_import(const char* text_h);
 /* name of the tiling the autotuner chose for that dominant layer (static string owned by ctx) */
 const char* pp_dominant_kernel(pp_ctx* ctx);
 int pp_version(void);

@@ -529,11 +529,17 @@ def sigmoid_f32(x):
 
 
 def postprocess(cls_preds, box_preds, dir_preds, anchors_mask, anchors, class_masks, center_limit,
-                nms_mode="aabb"):
+                nms_mode="aabb", detail=False, nms_fn=None):
     """Per class: anchor mask -> sigmoid -> score >= 0.05 -> top-1000 -> decode -> standup
     AABB -> NMS(0.1) -> first 300 -> direction flip -> range mask (quirk: dims vs upper
     limits, :107-109) -> limit_period(2*pi).  Returns (det f32[k,9] rows
-    x,y,z,l,w,h,r,score,class_index , per-class counts)."""
+    x,y,z,l,w,h,r,score,class_index , per-class counts).
+    detail=True additionally returns, per class, the intermediate selections (test diagnostics: which
+    anchors were candidates / kept, so a differing detection can be traced to the decision that flipped):
+    dict(idx top-k anchor ids in score order, score, dets NMS input, keep positions into idx (all NMS
+    survivors, before the 300 cut), final anchor id per output row).  nms_fn(dets, thr) overrides the NMS
+    implementation (the C oracle for large candidate sets)."""
+    info = []
     cls_preds = np.asarray(cls_preds, dtype=F32).reshape(-1)
     box_preds = np.asarray(box_preds, dtype=F32).reshape(-1, 7)
     dir_preds = np.asarray(dir_preds, dtype=F32).reshape(-1, 2)
@@ -547,7 +553,9 @@ def postprocess(cls_preds, box_preds, dir_preds, anchors_mask, anchors, class_ma
         idx, sc = idx[keep], sc[keep]
         if idx.size == 0:
             counts.append(0)
+            info.append(dict(idx=idx, score=sc, dets=np.zeros((0, 5), F32), keep=np.zeros(0, np.int64), final=idx, n_cand=0))
             continue
+        n_cand = int(idx.size)
         # topk: score descending, ties by lower anchor index (torch.topk leaves ties unspecified)
         o = np.lexsort((idx, -sc.astype(np.float64)))[:NMS_PRE_MAX]
         idx, sc = idx[o], sc[o]
@@ -556,19 +564,22 @@ def postprocess(cls_preds, box_preds, dir_preds, anchors_mask, anchors, class_ma
         if nms_mode == "aabb":
             corners = center_to_corner_box2d(boxes[:, :2], boxes[:, 3:5], boxes[:, 6])
             dets = np.concatenate([corner_to_standup_nd(corners), sc[:, None]], axis=1)
-            sel = nms_aabb(dets, NMS_IOU_THR)[:NMS_POST_MAX]
+            keep_all = (nms_fn or nms_aabb)(dets, NMS_IOU_THR)
         else:
             dets = np.concatenate([boxes[:, [0, 1, 3, 4, 6]], sc[:, None]], axis=1)
-            sel = nms_rotated(dets, NMS_IOU_THR)[:NMS_POST_MAX]
-        sel = np.asarray(sel, dtype=np.int64)
+            keep_all = (nms_fn or nms_rotated)(dets, NMS_IOU_THR)
+        sel = np.asarray(keep_all[:NMS_POST_MAX], dtype=np.int64)
         b = boxes[sel].copy()
         s_sel = sc[sel]
         opp = (b[:, 6] > 0) ^ dirl[sel]
         b[:, 6] = (b[:, 6].astype(np.float64) + np.where(opp, np.pi, 0.0)).astype(F32)  # :101 (f64 add, f32 store)
         rm = np.any(b[:, :3] > lim[:3], axis=1) & np.any(b[:, 3:6] < lim[3:], axis=1)
         b, s_sel = b[rm], s_sel[rm]
+        info.append(dict(idx=idx, score=sc, dets=dets, keep=np.asarray(keep_all, dtype=np.int64), final=idx[sel][rm], n_cand=n_cand))
         b[:, 6] = limit_period(b[:, 6], 0.5, 2 * np.pi)
         rows.append(np.concatenate([b, s_sel[:, None], np.full((b.shape[0], 1), ci, dtype=F32)], axis=1))
         counts.append(int(b.shape[0]))
     det = np.concatenate(rows, axis=0).astype(F32) if rows else np.zeros((0, 9), dtype=F32)
+    if detail:
+        return det, counts, info
     return det, counts

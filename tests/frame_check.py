@@ -1,0 +1,188 @@
+"""Whole-frame parity checker shared by the GPU frame tests.
+
+The north-star bar is "box regressions and scores within 1e-3".  A whole frame also contains integer
+decisions (score >= 0.05, top-1000, NMS at IoU 0.1, first 300, range mask, direction flip) that a 1e-5
+deviation of a logit can flip when a margin is that small, and a flipped decision changes WHICH rows
+exist, not a row's values.  Instead of tolerating a blanket fraction of unmatched rows, compare_frame():
+
+ 1. checks the GPU's integer outputs exactly (anchor mask);
+ 2. bounds the deviation of EVERY head logit (cls / box / dir, all anchors) against the oracle's;
+ 3. re-runs the oracle's post-processing on the GPU's own logits and requires the GPU's detections to
+    be that result exactly (selection is integer work -> same rows, boxes <= 2e-5);
+ 4. matches reference and GPU detections by ANCHOR ID; every common row must agree within 1e-3 on all
+    eight fields (angle modulo 2*pi; a pi flip only with a tied direction logit; for a box whose largest
+    coordinate / size exceeds 1 m the six metric fields are relative to it: size = exp(regression) * anchor);
+ 5. every row present on one side only must be EXPLAINED by a decision whose margin is below the
+    bound implied by step 2 (threshold / top-k boundary / NMS IoU at the threshold / score-order swap
+    of two overlapping boxes / cascade from an explained flip / range-mask limit).  Unexplained rows fail.
+
+The observed numbers (deviations, matched, differing, explained) are returned and printed.
+"""
+import numpy as np
+
+from oracle import c_oracle as C
+from oracle import pp_oracle as O
+
+F32 = np.float32
+TOL = 1e-3          # north-star tolerance on box fields and scores
+SCORE_THR, IOU_THR, PRE_MAX, POST_MAX = 0.05, 0.1, 1000, 300
+
+
+def oracle_frame(synth, name, pts, sd, norm="instance", num_anchor_per_loc=9, setup=None, anchors=None):
+    """voxelise -> mask -> PFN -> scatter -> backbone -> head on the CPU oracle (logits, not detections)."""
+    cfg = synth.load_config(name)
+    s = setup or O.voxel_setup(cfg)
+    a = anchors or O.make_anchors(s)
+    v, c, n = C.points_to_voxels(pts, s["voxel_size"], s["offset"], s["grid_size"], cfg["max_voxels"], cfg["max_num_points"])
+    mask = C.create_mask(c, s["grid_size"], a["anchors_coors"])
+    feat = O.pfn(v, n, c, sd, s)
+    rpn = O.backbone(O.scatter(feat, c, s["grid_size"]), sd, norm)
+    cls, box, dr = O.head(rpn, sd, num_anchor_per_loc)
+    return dict(cls=np.asarray(cls, F32).reshape(-1), box=np.asarray(box, F32).reshape(-1, 7), dir=np.asarray(dr, F32).reshape(-1, 2),
+                mask=mask, rpn=rpn, feat=feat, coors=c, anchors=a["anchors"], class_masks=a["class_masks"],
+                center_limit=cfg["center_limit"])
+
+
+def _pair_iou(da, db, rotated):
+    if rotated:
+        return np.array([C.rotated_iou(da[:5], b[:5]) for b in db], dtype=np.float64)
+    one = 1.0
+    da = da.astype(np.float64)
+    db = db.astype(np.float64)
+    w = np.maximum(np.minimum(da[2], db[:, 2]) - np.maximum(da[0], db[:, 0]) + one, 0)
+    h = np.maximum(np.minimum(da[3], db[:, 3]) - np.maximum(da[1], db[:, 1]) + one, 0)
+    inter = w * h
+    sa = (da[2] - da[0] + one) * (da[3] - da[1] + one)
+    sb = (db[:, 2] - db[:, 0] + one) * (db[:, 3] - db[:, 1] + one)
+    return inter / (sa + sb - inter)
+
+
+def _angle_dev(a, b):
+    d = (np.asarray(a, np.float64) - np.asarray(b, np.float64) + np.pi) % (2 * np.pi) - np.pi
+    return np.abs(d)
+
+
+def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_tol=TOL):
+    """ref / gpu: dicts with cls[A], box[A,7], dir[A,2], mask[A] (+ anchors, class_masks, center_limit in ref).
+    det_gpu f32[k,9], cnt_gpu int[1+ncls].  Returns the report dict; raises AssertionError on any violation."""
+    rotated = nms_mode in ("rotated", 1)
+    mode = "rotated" if rotated else "aabb"
+    nms_fn = C.nms_rotated if rotated else C.nms_aabb
+    anchors, class_masks, lim = ref["anchors"], ref["class_masks"], ref["center_limit"]
+    ncls = len(class_masks)
+    rep = {"label": label}
+    # 1. integer stage
+    assert np.array_equal(np.asarray(gpu["mask"]).astype(bool), np.asarray(ref["mask"]).astype(bool)), f"{label}: anchor mask differs"
+    # 2. every logit
+    m = np.asarray(ref["mask"]).astype(bool)
+    rep["dev_cls"] = float(np.abs(gpu["cls"] - ref["cls"]).max())
+    rep["dev_box"] = float(np.abs(gpu["box"] - ref["box"]).max())
+    rep["dev_dir"] = float(np.abs(gpu["dir"] - ref["dir"]).max())
+    assert max(rep["dev_cls"], rep["dev_box"], rep["dev_dir"]) <= logit_tol, (label, rep)
+    # 3. the GPU's post-processing is exact on its own logits
+    det_self, counts_self, info_g = O.postprocess(gpu["cls"], gpu["box"], gpu["dir"], m, anchors, class_masks, lim, mode, detail=True, nms_fn=nms_fn)
+    assert list(np.asarray(cnt_gpu)[1:1 + ncls]) == counts_self, (label, "selection differs from the oracle run on the GPU's own logits",
+                                                                  list(np.asarray(cnt_gpu)[:1 + ncls]), counts_self)
+    assert int(np.asarray(cnt_gpu)[0]) == sum(counts_self) == det_gpu.shape[0]
+    rep["post_self_dev"] = float(np.abs(det_gpu - det_self).max()) if det_self.size else 0.0
+    assert rep["post_self_dev"] <= 2e-5, (label, rep)
+    # 4./5. against the reference detections
+    det_ref, counts_ref, info_r = O.postprocess(ref["cls"], ref["box"], ref["dir"], m, anchors, class_masks, lim, mode, detail=True, nms_fn=nms_fn)
+    rep["n_ref"], rep["n_gpu"] = int(det_ref.shape[0]), int(det_gpu.shape[0])
+    eps_s = rep["dev_cls"] + 1e-7         # sigmoid' <= 1/4: a 4x margin on the score deviation
+    eps_iou = 64.0 * rep["dev_box"] + 1e-5  # decode scales a box logit by <= ~14 m (anchor diagonal); narrowest box ~0.6 m wide
+    eps_dir = 2.0 * rep["dev_dir"] + 1e-7
+    matched, max_dev, differing, explained, why = 0, 0.0, 0, 0, []
+    off_r = off_g = 0
+    for ci in range(ncls):
+        R, G = info_r[ci], info_g[ci]
+        rows_r = det_ref[off_r:off_r + counts_ref[ci]]
+        rows_g = det_gpu[off_g:off_g + counts_self[ci]]
+        off_r += counts_ref[ci]
+        off_g += counts_self[ci]
+        pos_r = {int(a): i for i, a in enumerate(R["final"])}
+        pos_g = {int(a): i for i, a in enumerate(G["final"])}
+        for a, i in pos_r.items():
+            j = pos_g.get(a)
+            if j is None:
+                continue
+            d = np.abs(rows_g[j, :8] - rows_r[i, :8])
+            d[6] = _angle_dev(rows_g[j, 6], rows_r[i, 6])
+            if d[6] > TOL and abs(d[6] - np.pi) <= TOL:  # direction flip: only with a tied direction logit or angle ~ 0
+                tied = abs(float(ref["dir"][a, 1]) - float(ref["dir"][a, 0])) <= eps_dir
+                assert tied, (label, "unexplained pi flip", a, rows_r[i], rows_g[j])
+                d[6] = 0.0
+                why.append((ci, a, "dir-tie"))
+            # sizes are exp(regression) * anchor size and z carries -h/2: the 1e-3 bound on the regressions is a RELATIVE
+            # 1e-3 on a box whose extent exceeds 1 m (random-init heads emit 50-250 m boxes); angle and score are absolute
+            d[:6] /= max(1.0, float(np.abs(rows_r[i, :6]).max()))
+            assert d.max() <= TOL, (label, "matched row deviates", a, rows_r[i], rows_g[j])
+            max_dev = max(max_dev, float(d.max()))
+            matched += 1
+        # rows on one side only
+        cand_r, cand_g = set(map(int, R["idx"])), set(map(int, G["idx"]))
+        kept_r, kept_g = set(map(int, R["idx"][R["keep"]])), set(map(int, G["idx"][G["keep"]]))
+        fin_r, fin_g = set(pos_r), set(pos_g)
+        S = (cand_r ^ cand_g) | (kept_r ^ kept_g) | (fin_r ^ fin_g)
+        differing += len(fin_r ^ fin_g)
+        if not S:
+            continue
+        ir = {int(a): i for i, a in enumerate(R["idx"])}
+        ig = {int(a): i for i, a in enumerate(G["idx"])}
+        score = lambda a: float(R["score"][ir[a]]) if a in ir else float(G["score"][ig[a]])
+        dets_of = lambda a: R["dets"][ir[a]] if a in ir else G["dets"][ig[a]]
+        union = sorted(cand_r | cand_g, key=lambda a: -score(a))
+        udets = np.stack([dets_of(a) for a in union]) if union else np.zeros((0, 5), F32)
+        uscore = np.array([score(a) for a in union])
+        done = {}
+        for a in sorted(S, key=lambda a: -score(a)):
+            s_a, reason = score(a), None
+            if a in (cand_r ^ cand_g):
+                kth = []
+                for info in (R, G):
+                    if info["n_cand"] > PRE_MAX:
+                        kth.append(float(info["score"][-1]))
+                if abs(s_a - SCORE_THR) <= eps_s:
+                    reason = "score-threshold"
+                elif any(abs(s_a - k) <= eps_s for k in kth):
+                    reason = "topk-boundary"
+            elif a in (kept_r ^ kept_g):
+                iou = _pair_iou(dets_of(a), udets, rotated)
+                for b, v, s_b in zip(union, iou, uscore):
+                    if b == a or s_b < s_a - eps_s:
+                        continue
+                    if abs(v - IOU_THR) <= eps_iou:
+                        reason = "iou-at-threshold"
+                    elif v > IOU_THR - eps_iou and abs(s_b - s_a) <= eps_s:
+                        reason = "score-order-swap"
+                    elif v > IOU_THR - eps_iou and done.get(b):
+                        reason = "cascade"
+                    if reason:
+                        break
+            else:  # survived both NMS runs, differs after the 300 cut / range mask
+                if any(done.get(b) and score(b) >= s_a - eps_s for b in S if b != a):
+                    reason = "cut-after-explained-flip"
+                else:
+                    box = O.box_decode(ref["box"][a:a + 1], anchors[a:a + 1])[0]
+                    l = np.asarray(lim, np.float64)
+                    if np.min(np.abs(np.concatenate([box[:3] - l[:3], box[3:6] - l[3:]]))) <= TOL:
+                        reason = "range-limit"
+            done[a] = reason
+            if a in (fin_r ^ fin_g) or reason is None:
+                if reason:
+                    explained += 1 if a in (fin_r ^ fin_g) else 0
+                    why.append((ci, a, reason))
+                else:
+                    raise AssertionError((label, "unexplained difference", dict(cls=ci, anchor=a, score=s_a, in_ref=a in fin_r, in_gpu=a in fin_g,
+                                                                               eps_s=eps_s, eps_iou=eps_iou)))
+    rep.update(matched=matched, max_matched_dev=max_dev, differing=differing, explained=explained, why=why[:12])
+    assert explained == differing, (label, rep)
+    print(f"[frame parity] {label}: ref {rep['n_ref']} / gpu {rep['n_gpu']} detections, {matched} matched by anchor id (max dev {max_dev:.2e}), "
+          f"{differing} differing rows all explained {sorted(set(w[2] for w in why))}; logit dev cls {rep['dev_cls']:.2e} box {rep['dev_box']:.2e} "
+          f"dir {rep['dev_dir']:.2e}; post-proc on own logits dev {rep['post_self_dev']:.1e}")
+    return rep
+
+
+def gpu_logits(eng, frame):
+    return dict(cls=eng.fetch(frame, "cls").cpu().numpy(), box=eng.fetch(frame, "box").cpu().numpy(), dir=eng.fetch(frame, "dir").cpu().numpy(),
+                mask=eng.fetch(frame, "mask").cpu().numpy().astype(bool))

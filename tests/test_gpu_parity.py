@@ -259,89 +259,64 @@ def test_nms_aabb_large_vs_oracle(fw):
     assert fw["nms"].nms_gpu(d, 0.1) == C.nms_aabb(d, 0.1)
 
 
+def _exact_iou(b1, b2):
+    """fp64 IoU of two rotated boxes (cx,cy,dx,dy,angle) by Sutherland-Hodgman clipping: an arbiter that has no
+    in/out tests on fp32 corner coordinates."""
+    def corners(b):
+        c, s = np.cos(float(b[4])), np.sin(float(b[4]))
+        pts = np.array([[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]]) * np.array([float(b[2]), float(b[3])])
+        return pts @ np.array([[c, -s], [s, c]]) + np.array([float(b[0]), float(b[1])])  # eval/iou.py:351-374: x' = c x + s y, y' = -s x + c y
+
+    def area(p):
+        return 0.5 * abs(sum(p[i][0] * p[(i + 1) % len(p)][1] - p[(i + 1) % len(p)][0] * p[i][1] for i in range(len(p)))) if len(p) >= 3 else 0.0
+
+    poly, clip = [tuple(x) for x in corners(b1)], corners(b2)
+    if area(list(map(tuple, clip))) and np.cross(clip[1] - clip[0], clip[2] - clip[1]) < 0:
+        clip = clip[::-1]
+    for i in range(4):
+        a_, b_ = clip[i], clip[(i + 1) % 4]
+        e = b_ - a_
+        out = []
+        for j in range(len(poly)):
+            p_, q_ = np.array(poly[j]), np.array(poly[(j + 1) % len(poly)])
+            sp, sq = np.cross(e, p_ - a_), np.cross(e, q_ - a_)
+            if sp >= 0:
+                out.append(tuple(p_))
+            if (sp >= 0) != (sq >= 0):
+                t = sp / (sp - sq)
+                out.append(tuple(p_ + t * (q_ - p_)))
+        poly = out
+        if not poly:
+            break
+    inter = area(poly)
+    a1, a2 = float(b1[2]) * float(b1[3]), float(b2[2]) * float(b2[3])
+    return inter / (a1 + a2 - inter)
+
+
 def test_rotated_iou_and_nms(fw):
     g = golden("nms_rotated")
     m = fw["nms"].rotate_iou_gpu(g["boxes"], g["boxes"])
     ok = np.isfinite(g["iou"])
-    assert np.mean(np.abs(m[ok] - g["iou"][ok]) < 1e-4) > 0.995  # sinf/cosf ulps flip a few degenerate pairs
+    dev = np.abs(m - g["iou"])
+    out = np.argwhere(ok & ~(dev < 1e-4))
+    # devRotateIoU decides "corner inside the other box" on fp32 coordinates: where a corner lies ON an edge (identical /
+    # edge-sharing boxes) one ulp of sinf/cosf flips the test and a whole triangle of the intersection polygon.  Every pair
+    # that leaves the 1e-4 band must therefore be such a pair -- shown by an fp64 clipping arbiter: the reference's own
+    # value is at least as far from the true IoU as ours is from the reference -- and there may be only a handful.
+    worst = 0.0
+    for i, j in out:
+        ex = _exact_iou(g["boxes"][i], g["boxes"][j])
+        e_gpu, e_ref = abs(float(m[i, j]) - ex), abs(float(g["iou"][i, j]) - ex)
+        worst = max(worst, e_gpu)
+        assert e_gpu <= 1e-4 or e_ref > 1e-4, (i, j, float(m[i, j]), float(g["iou"][i, j]), ex)
+    print(f"[rotated iou] {ok.sum()} finite pairs, max dev inside band {dev[ok & (dev < 1e-4)].max():.2e}, {len(out)} degenerate pairs "
+          f"(GPU vs fp64 arbiter worst {worst:.2e})")
+    assert len(out) <= 0.005 * ok.sum()
     assert fw["nms"].rotate_nms_gpu(g["dets"], 0.1) == [int(v) for v in g["keep"]]
     assert fw["nms"].rotate_nms_gpu(g["dets200"], 0.1) == [int(v) for v in g["keep200"]]
 
 
-# ------------------------------------------------------------------ a10/a15 whole frame
-def ref_rows(g):
-    return np.concatenate([g["location"], g["dimensions"], g["rotation_y"][:, None], g["score"][:, None],
-                           g["cls_idx"][:, None].astype(np.float32)], axis=1)
-
-
-def match_fraction(det, ref, tol):
-    used = np.zeros(det.shape[0], dtype=bool)
-    ok = 0
-    for r in ref:
-        d = np.abs(det[:, :8] - r[None, :8]).max(axis=1) + (det[:, 8] != r[8]) * 1e3 + used * 1e3
-        j = int(np.argmin(d))
-        if d[j] <= tol:
-            used[j] = True
-            ok += 1
-    return ok / max(ref.shape[0], 1)
-
-
-@pytest.mark.parametrize("tag,cls_bias", [("rand", None), ("trained", -4.6)])
-def test_frame_dropin_vs_reference(tag, cls_bias, fw, synth):
-    """The reference's own loop (train.py:222-237) on the drop-in classes, compared with the annos
-    the reference produced for the same cloud and weights."""
-    g = golden(f"e2e_eight_20cm_{tag}")
-    cfg = make_cfg(synth, "eight_20cm")
-    voxel_generator = fw["vg"].VoxelGenerator(cfg)
-    anchor_assigner = fw["aa"].AnchorAssigner(cfg)
-    inference = fw["inf"].Inference(cfg, anchor_assigner)
-    infer_data = fw["ds"].InferData(cfg, voxel_generator, anchor_assigner, torch.float32)
-    net = fw["shared"].PointPillars(cfg)
-    net.to(cfg["device"])
-    net.load_state_dict(synth.seeded_state_dict(0, cls_bias=cls_bias))
-    net.eval()
-    points = synth.lidar_cloud("eight_20cm", seed=1000)
-    example = infer_data.get(points)
-    with torch.no_grad():
-        preds = net(example)
-    annos = inference.infer_gpu(example, preds)[0]
-    # network numerics at sampled positions (tolerance 1e-3 abs: the north-star bound; observed ~1e-5)
-    feat = net.pillar_point_net(example["voxels"], example["num_points_per_voxel"], example["coordinates"])
-    np.testing.assert_allclose(feat[:64].cpu().numpy(), g["pfn_rows"], atol=2e-5)
-    np.testing.assert_allclose(preds["cls_preds"].reshape(-1)[torch.from_numpy(g["pred_idx"]).cuda()].cpu().numpy(), g["cls_vals"], atol=1e-3)
-    np.testing.assert_allclose(preds["box_preds"].reshape(-1, 7)[torch.from_numpy(g["pred_idx"]).cuda()].cpu().numpy(), g["box_vals"], atol=1e-3)
-    np.testing.assert_allclose(preds["dir_preds"].reshape(-1, 2)[torch.from_numpy(g["pred_idx"]).cuda()].cpu().numpy(), g["dir_vals"], atol=1e-3)
-    ref = ref_rows(g)
-    names = list(anchor_assigner.class_masks.keys())
-    det = np.concatenate([annos["location"], annos["dimensions"], annos["rotation_y"][:, None], annos["score"][:, None],
-                          np.array([names.index(x) for x in annos["name"]], np.float32)[:, None]], axis=1)
-    # 1e-3 on every box field and score; near-tie reorderings in top-k/NMS may drop a few boxes
-    frac = match_fraction(det, ref, 1e-3)
-    assert abs(det.shape[0] - ref.shape[0]) <= max(3, ref.shape[0] // 100), (det.shape, ref.shape)
-    assert frac >= 0.99, frac
-
-
-@pytest.mark.parametrize("name,norm,nms_mode", [("eight_20cm", "instance", 1), ("nuscene", "batch", 0), ("nuscene", "instance", 0)])
-def test_fused_frame_vs_oracle(name, norm, nms_mode, fw, synth):
-    """pp_infer_frame (single call, no host sync) against the full CPU oracle, incl. rotated NMS and
-    the BatchNorm backbone."""
-    from test_oracle_e2e import run_oracle_frame
-    eng_mod = load_pkg("engine")
-    cfg = make_cfg(synth, name)
-    fw["vg"].VoxelGenerator(cfg)
-    sd = synth.seeded_state_dict(1, norm=norm, cls_bias=-3.0)
-    eng = eng_mod.Engine(cfg, norm=norm)
-    eng.load_state_dict(sd)
-    pts = synth.lidar_cloud(name, seed=77)
-    det, cnt = eng.infer_frame(torch.from_numpy(pts).cuda(), nms_mode=nms_mode)
-    cnt = cnt.cpu().numpy()
-    det = det[:cnt[0]].cpu().numpy()
-    r = run_oracle_frame(synth, name, 77, sd, norm=norm, nms_mode="rotated" if nms_mode else "aabb")
-    assert abs(det.shape[0] - r["det"].shape[0]) <= max(3, r["det"].shape[0] // 100)
-    assert match_fraction(det, r["det"], 1e-3) >= 0.99
-    assert list(cnt[1:4]) == r["counts"] or abs(int(cnt[0]) - sum(r["counts"])) <= 3
-
-
+# ------------------------------------------------------------------ a10/a15 whole frame: tests/test_gpu_frames.py
 def test_postprocess_stage_exact(fw, synth):
     """Post-processing fed with the ORACLE's head outputs: selection is integer work, so the kept
     anchors must match exactly and the boxes to 1e-5."""
