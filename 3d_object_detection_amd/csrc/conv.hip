@@ -1025,6 +1025,524 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 }
 
 // ------------------------------------------------------------------------------------------
+// wino4_mfma: Winograd F(2x2,3x3) re-structured around ONE wave per SIMD with the whole 512-register file.
+// What the counters said about wino_mfma (profiles/r01_pmc_sq_waits_and_mix.txt): 3.4 VALU + 1.1 LDS instructions
+// per MFMA, two waves per SIMD waiting on each other for issue (53 % of wave time), the matrix pipe 50 % busy;
+// the non-MFMA phases (chunk opening, epilogue) of two independent workgroups overlap only by chance.  Here:
+//  * MT = 4: a wave owns 16 tiles x ALL 64 output channels of the block (256 accumulator registers = the AGPR half).
+//    Each transformed B operand now feeds 4 MFMAs instead of 2, each A fetch is one ds_read_b128 for 4 MFMAs: per MFMA
+//    the transform VALU, the LDS reads and the staging work all halve, and a 64-channel layer transforms its
+//    input ONCE instead of once per 32-row block.
+//  * a THREE-deep LDS ring (input patch + weight image per channel chunk): chunk g+2 is written while chunk g is
+//    multiplied, so chunk g+1 is complete one barrier EARLIER than it is needed and its first operands (raw patch,
+//    A fragments, column pass) are fetched during the last steps of chunk g.  The MFMA stream runs across chunk
+//    boundaries without the opening bubble (LDS round trip -> normalise -> column pass -> first MFMA) that cost
+//    wino_mfma ~1 k of every ~7 k cycles; the one barrier per chunk has nothing waiting right behind it.
+//  * the staging pipeline runs across TILE boundaries too: the load side simply walks the (item, chunk) stream two
+//    chunks ahead of the compute side, whatever tile that is.
+//  * InstanceNorm (scale, shift) of the staged chunk come through the scalar cache (wave-uniform address), not LDS.
+//  * the statistics' cross-wave reduction is deferred behind the next tile's first chunk barrier: no extra barrier.
+// One workgroup (4 waves) per CU, persistent over the (cout block, tile, frame) list like wino_mfma.
+// ------------------------------------------------------------------------------------------
+// The 256 accumulator registers of wino4_mfma are NOT C++ values: its MFMAs name a[0:255] literally.  Handing hipcc 64 live
+// accumulator quads next to ~130 asm statements per chunk ends in accumulators scattered over both register halves, AGPR
+// permutations at the loop edge and scratch spills of just-loaded operands; with the accumulators out of its sight it
+// allocates < 256 plain VGPRs and nothing else.  Every such statement clobbers the whole AGPR half, so the compiler can never
+// park a value there (audit: no v_accvgpr_* outside these statements in the ISA, tools/isa_stats.py).
+#define W4_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define W4_A100(h) W4_A10(h##0), W4_A10(h##1), W4_A10(h##2), W4_A10(h##3), W4_A10(h##4), W4_A10(h##5), W4_A10(h##6), W4_A10(h##7), W4_A10(h##8), W4_A10(h##9)
+#define W4_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W4_A10(1), W4_A10(2), W4_A10(3), W4_A10(4), W4_A10(5), W4_A10(6), W4_A10(7), W4_A10(8), W4_A10(9), \
+                 W4_A100(1), W4_A10(20), W4_A10(21), W4_A10(22), W4_A10(23), W4_A10(24), "a250", "a251", "a252", "a253", "a254", "a255"
+template <int R>
+__device__ __forceinline__ float w4_acc_read()
+{
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(R) : W4_AGPRS);
+    return v;
+}
+
+#if defined(PP_W4_DIAG) && (PP_W4_DIAG & 32)
+#define W4_PAD ""
+#else
+#define W4_PAD "s_nop 1\n\t"
+#endif
+#ifndef PP_W4_DIAG
+#define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
+#endif
+template <int TWT, int BTX, int KC>
+struct Wino4Cfg {
+    static constexpr int WN = 4, MT = 4;
+    static constexpr int THT = 16 / TWT;
+    static constexpr int BTY = WN / BTX;
+    static constexpr int PW = BTX * TWT * 2, PH = BTY * THT * 2;
+    static constexpr int IW = PW + 2, IH = PH + 2;
+    static constexpr int HALF = (IW + 1) / 2;
+    static constexpr int iwp()
+    {
+        int v = IW;
+        if (TWT == 16) return v;
+        while ((2 * v) % 32 != TWT) ++v;
+        return v;
+    }
+    static constexpr int IWP = iwp();
+    static constexpr int cs()
+    {
+        int v = IH * IWP;
+        while (v % 32 != 16) ++v;
+        return v;
+    }
+    static constexpr int CS = cs();
+    static constexpr int BM = 64;  // rows per block = MT * 16; A image row = [m 0..15][M-tile 0..3]: one ds_read_b128 per lane, the
+                                   // 64 lanes of a step read 1 KB contiguous (kq*64 + m*4 floats) -- conflict-free without padding
+    static constexpr int THREADS = 256;
+    static constexpr int NPOS = IH * IW;
+    static constexpr int PR = (NPOS + THREADS - 1) / THREADS;
+    static constexpr int W4 = 16 * KC * BM / 4;
+    static constexpr int WR = (W4 + THREADS - 1) / THREADS;
+    static constexpr int LDS_IN = KC * CS;
+    static constexpr int LDS_W = 16 * KC * BM;
+    static constexpr int NSTAGE = 3;
+    static constexpr int LDS_FLOATS = NSTAGE * (LDS_IN + LDS_W) + 2 * WN * BM + 2 * 640;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "must fit the 160 KB LDS");
+    static_assert(WN % BTX == 0, "tiles must form a rectangle");
+    static_assert(KC == 8, "the step schedule assumes two channel quads per chunk (tq parity, A ring)");
+    static_assert(W4 % THREADS == 0, "weight image is a whole number of float4 per thread");
+};
+
+template <int TWT, int BTX, int KC, int ROOFLINE = 0>
+__global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
+{
+    using C = Wino4Cfg<TWT, BTX, KC>;
+    constexpr int MT = 4, WN = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* il = smem;                               // [3][KC][CS]
+    float* wl = il + C::NSTAGE * C::LDS_IN;         // [3][16][KC][64]
+    float* red = wl + C::NSTAGE * C::LDS_W;         // [WN][BM][2]
+    float* aff = red + 2 * WN * C::BM;              // [2 frame parities][2: scale, shift][320]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+
+    const int nbx = (p.Wout + C::PW - 1) / C::PW, nby = (p.Hout + C::PH - 1) / C::PH;
+    const int ntile = nbx * nby, ncb = (p.Cout + C::BM - 1) / C::BM;
+    const int total = ntile * ncb * p.nb;
+    const int per = (total + 7) >> 3;
+    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int lin_end = min(total, (xk + 1) * per);
+    const int lin0 = xk * per + xj;
+    if (lin0 >= lin_end) return;
+    const int nchunk = p.Cin / KC;
+
+    // ---------------- load side: walks the (item, chunk) stream two chunks ahead of the compute side ----------------
+    int goff[C::PR], loff[C::PR];
+    unsigned vmask = 0u;
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned plane_b = (unsigned)(p.Hin * p.Win) * 4u;
+    unsigned wbase_b = 0u;
+    float xv[C::PR][KC];
+    f32x4 wv[C::WR];
+#pragma unroll
+    for (int r = 0; r < C::PR; ++r) {
+        const int pos = min(tid + r * C::THREADS, C::NPOS - 1); // tail threads duplicate the last position: unconditional staging
+        const int iy = pos / C::IW, ix = pos - iy * C::IW;
+        loff[r] = iy * C::IWP + (ix & 1) * C::HALF + (ix >> 1);
+    }
+    int s_lin = lin0, s_ch = 0, s_frame = 0; // chunk the NEXT load request is for, and its frame
+    int r_c0 = 0;                            // first channel of the chunk held in the registers (its table slot: r_tab)
+    unsigned r_vmask = 0u;
+    auto set_load_tile = [&](int l) {
+        const int cb_ = l % ncb, t_ = (l / ncb) % ntile, f_ = l / (ncb * ntile);
+        const int iy0_ = (t_ / nbx) * C::PH - 1, ix0_ = (t_ % nbx) * C::PW - 1;
+        vmask = 0u;
+#pragma unroll
+        for (int r = 0; r < C::PR; ++r) {
+            const int pos = min(tid + r * C::THREADS, C::NPOS - 1);
+            const int iy = pos / C::IW, ix = pos - iy * C::IW;
+            const int gy = iy0_ + iy, gx = ix0_ + ix;
+            const bool inb = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+            goff[r] = inb ? (gy * p.Win + gx) * 4 : 0;
+            vmask |= (inb ? 1u : 0u) << r;
+        }
+        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)f_ * p.in_fs), 0, 0x7FFFFFFF, 0x00020000);
+        wbase_b = (unsigned)((size_t)cb_ * nchunk * C::W4 * 16);
+        s_frame = f_;
+    };
+    // The load side: advance() -- uniform branches, possibly a new tile's offsets and a new frame's (scale, shift) table --
+    // runs at the top of a chunk, outside the MFMA stream (a branch between MFMA steps makes hipcc shuffle accumulators);
+    // the requests themselves are spread over the chunk's steps, each right behind the LDS write that frees its register, so
+    // every load has a whole chunk (> 4 k cycles) to land.  Past the end of this workgroup's list the load side stays on its
+    // last chunk (harmless duplicates into ring slots nobody reads; every request stays inside the tensors).
+    // (scale, shift) of the producer's normalisation live in LDS in TWO table slots: the load side may already be in another
+    // frame while older chunks are still being normalised.  A frame change of the load side flips the slot, writes the new
+    // frame's table there, and the chunk barrier that follows publishes it (that slot's previous table belongs to a frame
+    // whose last chunk was normalised at least a whole tile ago).
+    int s_tab = 0, r_tab = 0;
+    auto load_aff = [&](int f_) {
+        float* dst = aff + s_tab * 640;
+        for (int c = tid; c < p.Cin; c += C::THREADS) {
+            dst[c] = p.pre_scale[(size_t)f_ * p.aff_fs + c];
+            dst[320 + c] = p.pre_shift[(size_t)f_ * p.aff_fs + c];
+        }
+    };
+    auto advance = [&]() {
+        if (s_ch + 1 < nchunk) ++s_ch;
+        else if (s_lin + nloc < lin_end) {
+            const int f_old = s_frame;
+            s_lin += nloc; s_ch = 0; set_load_tile(s_lin);
+            if (s_frame != f_old) { s_tab ^= 1; load_aff(s_frame); }
+        }
+    };
+// request piece E of chunk (s_lin, s_ch) into its register
+#define W4_LOAD_PIECE(E)                                                                         \
+    {                                                                                            \
+        if constexpr ((E) < C::PR * KC) {                                                        \
+            constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
+            xv[r_][c_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[r_], (unsigned)(s_ch * KC + c_) * plane_b, 0)); \
+        } else if constexpr ((E) < C::PR * KC + C::WR) {                                         \
+            constexpr int r_ = (E) - C::PR * KC;                                                 \
+            wv[r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + r_ * C::THREADS) * 16, wbase_b + (unsigned)s_ch * (C::W4 * 16), 0)); \
+        }                                                                                        \
+    }
+// normalise + ReLU + zero padding of input piece E in place (SC/SH: this chunk's KC scales / shifts, MASK: its in-image bits)
+#define W4_NORM_PIECE(E, SC, SH, MASK)                                                           \
+    {                                                                                            \
+        if constexpr ((E) < C::PR * KC) {                                                        \
+            constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
+            xv[r_][c_] = fmaxf(fmaf(xv[r_][c_], SC[c_], SH[c_]), 0.f) * MASK[r_];               \
+        }                                                                                        \
+    }
+#define W4_READ_AFF(SC, SH, TAB, C0)                                                             \
+    {                                                                                            \
+        const float* t_ = aff + (TAB) * 640 + (C0);                                              \
+        _Pragma("unroll") for (int c = 0; c < KC; c += 4) {                                      \
+            const f32x4 a_ = *reinterpret_cast<const f32x4*>(t_ + c);                            \
+            const f32x4 b_ = *reinterpret_cast<const f32x4*>(t_ + 320 + c);                      \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) { SC[c + q] = a_[q]; SH[c + q] = b_[q]; } \
+        }                                                                                        \
+    }
+#define W4_WRITE_PIECE(E, IB, WB)                                                                \
+    {                                                                                            \
+        if constexpr ((E) < C::PR * KC) {                                                        \
+            constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
+            (IB)[c_ * C::CS + loff[r_]] = xv[r_][c_];                                            \
+        } else if constexpr ((E) < C::PR * KC + C::WR) {                                         \
+            constexpr int r_ = (E) - C::PR * KC;                                                 \
+            reinterpret_cast<f32x4*>(WB)[tid + r_ * C::THREADS] = wv[r_];                        \
+        }                                                                                        \
+    }
+#define W4_READ_RAW(DST, IB, C4)                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                         \
+            DST[i_ * 4 + j_] = (IB)[rbase + (C4) * 4 * C::CS + i_ * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
+// one row (4 values) of the raw 4x4 patch of the quad whose element index inside the ring is QB.  QB is made opaque once per
+// quad: otherwise hipcc folds the quad's offset into every row address and spends a v_add per ds_read2 on constants that no
+// longer fit the instruction's 8-bit offsets (the row offsets alone do: <= 3*IWP + HALF + 1 dwords)
+#define W4_READ_RAW_ROW(DST, QB, I)                                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                             \
+        DST[(I) * 4 + j_] = il[(QB) + (I) * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
+#define W4_COLPASS(T, D, K)                                                                      \
+    {                                                                                            \
+        constexpr int a_ = (K) / 4, j_ = (K) % 4;                                                \
+        if constexpr (a_ == 0) T[0 + j_] = D[0 + j_] - D[8 + j_];                                \
+        else if constexpr (a_ == 1) T[4 + j_] = D[4 + j_] + D[8 + j_];                           \
+        else if constexpr (a_ == 2) T[8 + j_] = D[8 + j_] - D[4 + j_];                           \
+        else T[12 + j_] = D[4 + j_] - D[12 + j_];                                                \
+    }
+#define W4_ROWPASS(T, XI)                                                                        \
+    (((XI) & 3) == 0 ? T[(XI)] - T[((XI) + 2) & 15] : ((XI) & 3) == 1 ? T[(XI)] + T[((XI) + 1) & 15] : ((XI) & 3) == 2 ? T[(XI)] - T[((XI) - 1) & 15] : T[((XI) - 2) & 15] - T[(XI)])
+
+    constexpr int NQ = KC / 4;                // 2
+    constexpr int NSTEP = NQ * 16;            // 32 steps of 4 MFMAs
+    constexpr int AD = 4;                     // A fragments in flight (3 steps = 384 matrix-pipe cycles ahead); NSTEP % AD == 0
+    constexpr int NPIECE = C::PR * KC + C::WR;
+    static_assert(NPIECE + 2 <= NSTEP, "staging does not fit the chunk's steps");
+
+    // this lane's tile inside the block patch (constant over items) and operand bases
+    const int btx = wn % BTX, bty = wn / BTX;
+    const int ttx = btx * TWT + (m % TWT), tty = bty * C::THT + (m / TWT);
+    const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
+    const int aoff = kq * C::BM + m * 4;
+
+    // ---------------- pipeline prologue: chunks 0 and 1 into ring slots 0 and 1, chunk 2 into the registers ----------------
+    set_load_tile(lin0);
+    load_aff(s_frame);
+    __syncthreads();
+    {
+        float sc_[KC], sh_[KC];
+        pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
+        W4_READ_AFF(sc_, sh_, s_tab, s_ch * KC)
+        float mk_[C::PR];
+#pragma unroll
+        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? 1.f : 0.f;
+        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il, wl) });
+        advance();
+        __syncthreads(); // a new frame's table (if the second chunk is already there)
+        pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
+        W4_READ_AFF(sc_, sh_, s_tab, s_ch * KC)
+#pragma unroll
+        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? 1.f : 0.f;
+        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il + C::LDS_IN, wl + C::LDS_W) });
+        advance();
+        pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
+        r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
+    }
+    __syncthreads();
+
+    float draw[16], tq[2][16];
+    f32x4 a[AD];
+    float vcur, vnext;
+    // first operands of the very first chunk (later chunks get theirs during their predecessor's last steps)
+    int qb = rbase;
+    pp_steps<0, 4>([&](auto I) { W4_READ_RAW_ROW(draw, qb, decltype(I)::value) });
+#pragma unroll
+    for (int s0 = 0; s0 < AD - 1; ++s0) a[s0] = *reinterpret_cast<const f32x4*>(wl + (s0 * KC) * C::BM + aoff);
+    pp_steps<0, 16>([&](auto K) { W4_COLPASS(tq[0], draw, decltype(K)::value) });
+    vnext = W4_ROWPASS(tq[0], 0);
+
+#if PP_WINO_STAMP
+    unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0;
+#endif
+    int buf = 0;                 // ring slot of the chunk being multiplied
+    bool pending = false;        // statistics of the previous tile wait in `red` for their cross-wave reduction
+    double* pend_dst = nullptr;
+    const size_t out_plane = (size_t)p.Hout * p.Wout;
+
+    for (int lin = lin0; lin < lin_end; lin += nloc) {
+        const int cb = lin % ncb, tile = (lin / ncb) % ntile;
+        const size_t fz = lin / (ncb * ntile);
+        const int co0 = cb * C::BM;
+        const int ox0 = (tile % nbx) * C::PW, oy0 = (tile / nbx) * C::PH;
+        const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
+
+        // accumulator quad of (M-tile i, Winograd position xi): a[(xi*4 + i)*4 .. +3].  The tile's first 16 steps take 0 as C:
+        // no zeroing pass over 256 registers; hence the chunk body exists twice (first chunk / accumulating chunks).
+        auto chunk_body = [&](auto FIRST, int ch) {
+            constexpr bool first_ = decltype(FIRST)::value;
+            const int nbuf = buf == 2 ? 0 : buf + 1, wbuf = buf == 0 ? 2 : buf - 1; // (buf+1)%3, (buf+2)%3
+            const float* ib = il + buf * C::LDS_IN;
+            const float* wb = wl + buf * C::LDS_W;
+            const float* ibn = il + nbuf * C::LDS_IN;
+            const float* wbn = wl + nbuf * C::LDS_W;
+            float* ibw = il + wbuf * C::LDS_IN;
+            float* wbw = wl + wbuf * C::LDS_W;
+            // the registers hold chunk g+2 (each piece requested a whole chunk ago): its (scale, shift) and in-image mask;
+            // then the load side moves on to chunk g+3, whose pieces are requested as the registers are freed
+#if PP_WINO_STAMP
+            unsigned long long st0_ = 0, st1_ = 0, st2_ = 0, st3_ = 0;
+            WN_STAMP(st0_)
+#endif
+            float sc_[KC], sh_[KC];
+            W4_READ_AFF(sc_, sh_, r_tab, r_c0)
+            float q_mask[C::PR]; // 1 inside the image, 0 on the zero padding (applied AFTER normalisation + ReLU)
+#pragma unroll
+            for (int r = 0; r < C::PR; ++r) q_mask[r] = ((r_vmask >> r) & 1u) ? 1.f : 0.f;
+            advance();
+            r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
+            WN_STAMP(st1_)
+            // One wave per SIMD issues IN ORDER: whatever follows an MFMA waits for that MFMA to enter the matrix pipe, and four
+            // MFMAs in a row leave the other instructions only the last one's 32 cycles (measured: the 32 steps took the SUM of
+            // the MFMA-only and the MFMA-free loop, 4.2 k + 2.5 k cycles per chunk).  So each step is MFMA, gap, MFMA, gap, ...:
+            //   gap A: the A fragment of step s+3 (one ds_read_b128)      gap B: raw patch row of the next quad / its column pass
+            //   gap C: row pass of step s+1's B operand, normalise piece s  gap D: LDS write of piece s + the request that refills it
+            // (<= 24 issue cycles per gap hide under the 32-cycle MFMA).  A B operand is written two gaps before its first use and
+            // the A fragments come from LDS behind hipcc's own lgkmcnt wait, so the asm MFMAs need no s_nop pad.
+#define W4_MFMA1(I, TAIL)                                                                        \
+            if constexpr (PP_W4_DIAG & 8) { asm volatile("" ::"v"(a[s_ % AD][I]), "v"(vcur)); }   \
+            else if constexpr (first_ && s_ < 16) {                                              \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" TAIL :: "v"(a[s_ % AD][I]), "v"(vcur), "i"((xi * 4 + I) * 4), "i"((xi * 4 + I) * 4 + 3) : W4_AGPRS); \
+            } else {                                                                             \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" TAIL :: "v"(a[s_ % AD][I]), "v"(vcur), "i"((xi * 4 + I) * 4), "i"((xi * 4 + I) * 4 + 3) : W4_AGPRS); \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
+            pp_steps<0, NSTEP>([&](auto S) {
+                constexpr int s_ = decltype(S)::value;
+                constexpr int c4 = s_ / 16, xi = s_ % 16;
+                vcur = vnext;
+                __builtin_amdgcn_sched_barrier(0);
+                W4_MFMA1(0, "")
+                if constexpr (!(PP_W4_DIAG & 4)) {   // gap A: A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
+                    constexpr int sa = s_ + AD - 1;
+                    if constexpr (sa < NSTEP) {
+                        constexpr int n4_ = sa / 16, nx_ = sa % 16;
+                        a[sa % AD] = *reinterpret_cast<const f32x4*>(wb + (nx_ * KC + n4_ * 4) * C::BM + aoff);
+                    } else {
+                        constexpr int sb = sa - NSTEP, n4_ = sb / 16, nx_ = sb % 16;
+                        a[sa % AD] = *reinterpret_cast<const f32x4*>(wbn + (nx_ * KC + n4_ * 4) * C::BM + aoff);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                W4_MFMA1(1, "")
+                // gap B: next quad (the next CHUNK's first quad from ring slot nbuf when this is the chunk's last quad): one raw
+                // patch row per step over steps 0..3, column pass over steps 6..13
+                if constexpr (xi < 4 && !(PP_W4_DIAG & 2)) {
+                    if constexpr (xi == 0) {
+                        qb = (c4 + 1 < NQ) ? buf * C::LDS_IN + rbase + (c4 + 1) * 4 * C::CS : nbuf * C::LDS_IN + rbase;
+                        asm volatile("" : "+v"(qb));
+                    }
+                    W4_READ_RAW_ROW(draw, qb, xi)
+                }
+                if constexpr (xi >= 6 && xi < 14) {
+                    if constexpr (PP_W4_DIAG & 1) {
+                        tq[(c4 + 1) & 1][(xi - 6) * 2] = draw[(xi - 6) * 2];
+                        tq[(c4 + 1) & 1][(xi - 6) * 2 + 1] = draw[(xi - 6) * 2 + 1];
+                    } else {
+                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
+                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                W4_MFMA1(2, "")
+                {   // gap C: row pass for step s_+1, normalisation of staging piece s_
+                    constexpr int c4n = (s_ + 1) / 16, xin = (s_ + 1) % 16;
+                    vnext = (PP_W4_DIAG & 1) ? tq[c4n & 1][xin] : W4_ROWPASS(tq[c4n & 1], xin);
+                    if constexpr (s_ < NPIECE && !(PP_W4_DIAG & 16)) { W4_NORM_PIECE(s_, sc_, sh_, q_mask) }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // The chunk's LAST MFMA carries the 12 wait states an 8-pass MFMA's D needs before anything but the next
+                // accumulating MFMA touches it (the epilogue's v_accvgpr_read after the last chunk; hipcc pads nothing behind an asm).
+                if constexpr (s_ + 1 < NSTEP) { W4_MFMA1(3, "") } else { W4_MFMA1(3, "\n\ts_nop 11") }
+                // gap D: staging of chunk g+2 into ring slot wbuf, and the request that refills the register with chunk g+3's piece
+                if constexpr (s_ < NPIECE) {
+                    if constexpr (!(PP_W4_DIAG & 16)) { W4_WRITE_PIECE(s_, ibw, wbw) }
+                    if constexpr (!(PP_W4_DIAG & 64)) { W4_LOAD_PIECE(s_) }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#undef W4_MFMA1
+            WN_STAMP(st2_)
+            __syncthreads();
+#if PP_WINO_STAMP
+            WN_STAMP(st3_)
+            sum_pre_ += st1_ - st0_; sum_steps_ += st2_ - st1_; sum_bar_ += st3_ - st2_; n_chunks_ += 1;
+#endif
+            buf = nbuf;
+            if (ch == 0 && pending) { // previous tile's statistics: every wave's partial sums are in `red` since before this barrier
+                if (tid < C::BM) {
+                    double s = 0.0, q = 0.0;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) {
+                        s += (double)red[(w * C::BM + tid) * 2];
+                        q += (double)red[(w * C::BM + tid) * 2 + 1];
+                    }
+                    atomicAdd(pend_dst + (size_t)tid * 2, s);
+                    atomicAdd(pend_dst + (size_t)tid * 2 + 1, q);
+                }
+                pending = false;
+            }
+        };
+        chunk_body(std::true_type{}, 0);
+#pragma unroll 1
+        for (int ch = 1; ch < nchunk; ++ch) chunk_body(std::false_type{}, ch);
+
+        // ---------------- epilogue: Y = A^T M A per lane, residual, float2 row stores, statistics ----------------
+#if PP_WINO_STAMP
+        unsigned long long se0_ = 0;
+        WN_STAMP(se0_)
+#endif
+        if (!(p.dbg & 4)) {
+        float* __restrict__ gout = p.out + fz * p.out_fs;
+        const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
+        const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
+        const bool two_y = opy + 1 < p.Hout;
+        const unsigned frame_bytes = (unsigned)((size_t)p.Cout * out_plane * 4);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(gout, 0, frame_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rres_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres ? gres : gout), 0, gres ? frame_bytes : 0u, 0x00020000);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const unsigned pixb = (unsigned)(((size_t)opy * p.Wout + opx) * 4);
+        // all residual rows are requested up front (buffer descriptor: lanes without a pixel / row and layers without a
+        // residual get zero records), so one memory latency is exposed per tile, not one per M-tile
+        unsigned off0[MT][4], off1[MT][4];
+        f32x2 r0[MT][4], r1[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co0 + i * 16 + kq * 4 + r;
+                const bool ok = pix_ok && row < p.Cout;
+                const unsigned o = (unsigned)((size_t)row * out_plane * 4) + pixb;
+                off0[i][r] = ok ? o : 0xFFFFFFFFu;
+                off1[i][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
+                r0[i][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off0[i][r], 0, 0));
+                r1[i][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off1[i][r], 0, 0));
+            }
+        pp_steps<0, MT>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            float ssum[4], ssq[4];
+            pp_steps<0, 4>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                float t0[4], t1[4];
+                pp_steps<0, 4>([&](auto A_) {
+                    constexpr int a_ = decltype(A_)::value;
+                    const float m0 = w4_acc_read<((a_ * 4 + 0) * 4 + i) * 4 + r>(), m1 = w4_acc_read<((a_ * 4 + 1) * 4 + i) * 4 + r>(),
+                                m2 = w4_acc_read<((a_ * 4 + 2) * 4 + i) * 4 + r>(), m3 = w4_acc_read<((a_ * 4 + 3) * 4 + i) * 4 + r>();
+                    t0[a_] = m0 + m1 + m2;
+                    t1[a_] = m1 - m2 - m3;
+                });
+                float y00 = t0[0] + t0[1] + t0[2], y01 = t1[0] + t1[1] + t1[2];
+                float y10 = t0[1] - t0[2] - t0[3], y11 = t1[1] - t1[2] - t1[3];
+                y00 += r0[i][r][0]; y01 += r0[i][r][1];
+                y10 += r1[i][r][0]; y11 += r1[i][r][1];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y00, y01}), rout, off0[i][r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y10, y11}), rout, off1[i][r], 0, 0);
+                const bool ok0 = off0[i][r] != 0xFFFFFFFFu, ok1 = off1[i][r] != 0xFFFFFFFFu;
+                float s_ = y00 + y01, q_ = y00 * y00 + y01 * y01; // same summation order as wino_mfma: row y, then row y+1
+                if (ok1) { s_ += y10; q_ += y10 * y10; s_ += y11; q_ += y11 * y11; }
+                ssum[r] = ok0 ? s_ : 0.f;
+                ssq[r] = ok0 ? q_ : 0.f;
+            });
+            if (p.stat_acc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
+                    if (m == 0) {
+                        const int lr = i * 16 + kq * 4 + r;
+                        red[(wn * C::BM + lr) * 2] = s;
+                        red[(wn * C::BM + lr) * 2 + 1] = q;
+                    }
+                }
+            }
+        });
+        if (p.stat_acc) {
+            pending = true;
+            pend_dst = p.stat_acc + fz * p.stat_fs + ((size_t)(blockIdx.x % NREP) * p.stat_C + co0) * 2;
+        }
+        } // dbg & 4 (timing ablation: no epilogue)
+#if PP_WINO_STAMP
+        { unsigned long long se1_ = 0; WN_STAMP(se1_) sum_epi_ += se1_ - se0_; n_tiles_ += 1; }
+#endif
+    }
+#if PP_WINO_STAMP
+    if (tid == 0 && p.dbg_buf) {
+        atomicAdd(&p.dbg_buf[0], sum_pre_); atomicAdd(&p.dbg_buf[1], sum_steps_); atomicAdd(&p.dbg_buf[2], sum_bar_);
+        atomicAdd(&p.dbg_buf[3], sum_epi_); atomicAdd(&p.dbg_buf[4], n_chunks_); atomicAdd(&p.dbg_buf[5], n_tiles_);
+    }
+#endif
+    if (pending) {
+        __syncthreads();
+        if (tid < C::BM && blockIdx.x >= 0) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                s += (double)red[(w * C::BM + tid) * 2];
+                q += (double)red[(w * C::BM + tid) * 2 + 1];
+            }
+            atomicAdd(pend_dst + (size_t)tid * 2, s);
+            atomicAdd(pend_dst + (size_t)tid * 2 + 1, q);
+        }
+    }
+#undef W4_LOAD_PIECE
+#undef W4_NORM_PIECE
+#undef W4_READ_AFF
+#undef W4_READ_RAW_ROW
+#undef W4_WRITE_PIECE
+#undef W4_READ_RAW
+#undef W4_COLPASS
+#undef W4_ROWPASS
+}
+
+// ------------------------------------------------------------------------------------------
 // Winograd with the WHOLE transformed weight slab resident in LDS (160 KB per CU on gfx950):
 //   16 positions x CIN x BM floats = 128 KB for CIN*BM = 2048 (CIN 64 x 32 rows, CIN 128 x 16 rows).
 // * persistent workgroups (one per CU, 8 waves): the slab is loaded once per launch, never re-staged
@@ -1725,6 +2243,20 @@ Variant make_wino(bool roofline_layer)
     return v;
 }
 
+template <int TWT, int BTX, int KC>
+Variant make_wino4(bool roofline_layer)
+{
+    using C = Wino4Cfg<TWT, BTX, KC>;
+    Variant v;
+    v.kern = roofline_layer ? wino4_mfma<TWT, BTX, KC, 1> : wino4_mfma<TWT, BTX, KC, 0>;
+    v.bm = C::BM; v.bmp = C::BM; v.pw = C::PW; v.ph = C::PH; v.kc = KC; v.threads = C::THREADS;
+    v.waves = 4; v.pairs = 4 * 16;
+    v.lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    v.wino = 4;
+    snprintf(v.name, sizeof(v.name), "wino4 tw%d bx%d kc%d", TWT, BTX, KC);
+    return v;
+}
+
 template <int CIN, int MT, int NT>
 Variant make_wres()
 {
@@ -1850,6 +2382,10 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         // (8-wave 32-row tilings, WN = 8, were tried: 6-15 % slower than their 4-wave twins -- two lock-stepped waves per SIMD)
         menu.push_back(make_wino<8, 1, 4, 1, 4>(roofline_layer));
         menu.push_back(make_wino<4, 1, 4, 2, 4>(roofline_layer));
+        // one wave per SIMD, 64 rows, 3-deep ring (even maps, Cout a multiple of 64 only -- see variant_ok)
+        menu.push_back(make_wino4<4, 2, 8>(roofline_layer));       // 16x16 px
+        menu.push_back(make_wino4<8, 1, 8>(roofline_layer));       // 16x16 px, 8x2-tile N-tiles
+        menu.push_back(make_wino4<8, 2, 8>(roofline_layer));       // 32x8 px
         if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
         if (cin == 128) menu.push_back(make_wres<128, 1, 1>()); // 128 KB slab: 128 ch x 16 rows
     }
@@ -1866,7 +2402,7 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
     return cost;
 }
 
-bool variant_ok(const Variant& v, int rows) { return v.wino == 2 ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
+bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -1954,7 +2490,7 @@ int pack_layer(pp_ctx* ctx, Layer& L)
     }
     L.rows = rows;
     int taps_eff = taps;
-    if (v.wino == 1 || v.wino == 2) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
+    if (v.wino == 1 || v.wino == 2 || v.wino == 4) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         std::vector<float> u((size_t)rows * L.cin * 16);
         for (size_t rc = 0; rc < (size_t)rows * L.cin; ++rc) {
@@ -2015,7 +2551,8 @@ int pack_layer(pp_ctx* ctx, Layer& L)
                         const int row = b * v.bm + mm;
                         if (row >= rows) continue;
                         // Winograd image: row = [wm][m][M-tile] so a lane's two A operands are adjacent (ds_read_b64)
-                        const int col = (v.wino == 1) ? ((mm >> 5) * 32 + (mm & 15) * 2 + ((mm >> 4) & 1)) : mm;
+                        // wino4 image: row = [m][M-tile 0..3] so a lane's four A operands are one ds_read_b128
+                        const int col = (v.wino == 1) ? ((mm >> 5) * 32 + (mm & 15) * 2 + ((mm >> 4) & 1)) : (v.wino == 4) ? ((mm & 15) * 4 + (mm >> 4)) : mm;
                         pk[((((size_t)b * nchunk + ch) * taps_eff + t) * v.kc + k) * v.bmp + col] =
                             rowsW[((size_t)row * L.cin + ch * v.kc + k) * taps_eff + t];
                     }
@@ -2092,6 +2629,13 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         const int ncb = pp_div_up(L.rows, v.bm);
         int g = (net->num_cu / ncb) * ncb;
         if (g < ncb) g = ncb;
+        grid = dim3(g, 1, 1);
+    }
+    if (v.wino == 4) { // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs
+        const int total = (int)grid.x * (int)grid.y * B;
+        int g = net->num_cu;
+        if (g > total) g = total;
+        g = (g + 7) & ~7;
         grid = dim3(g, 1, 1);
     }
     if (v.wino == 1) { // persistent Winograd: two workgroups per CU (LDS and registers allow exactly two), a multiple of the 8 XCDs
@@ -2206,7 +2750,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
-            if (variant_ok(v, rows) && strstr(v.name, force)) { L.var = v; return 0; }
+            if (variant_ok(v, rows) && !(v.wino == 4 && (Wout & 1)) && strstr(v.name, force)) { L.var = v; return 0; }
     }
     auto hit = tune_cache().find(sig);
     if (hit != tune_cache().end()) {
@@ -2245,6 +2789,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     std::vector<std::pair<double, const Variant*>> timed;
     for (const Variant& v : menu) {
         if (!variant_ok(v, rows)) continue;
+        if (v.wino == 4 && (Wout & 1)) continue; // float2 row stores
         const size_t need = (v.wino == 3) ? g1_lds(v, L.cin) : v.lds;
         if (need > 160 * 1024) continue;
         double ms;

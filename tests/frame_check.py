@@ -84,7 +84,8 @@ def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_t
     assert list(np.asarray(cnt_gpu)[1:1 + ncls]) == counts_self, (label, "selection differs from the oracle run on the GPU's own logits",
                                                                   list(np.asarray(cnt_gpu)[:1 + ncls]), counts_self)
     assert int(np.asarray(cnt_gpu)[0]) == sum(counts_self) == det_gpu.shape[0]
-    rep["post_self_dev"] = float(np.abs(det_gpu - det_self).max()) if det_self.size else 0.0
+    # relative above 1 m: random-init heads emit boxes thousands of metres long, where one fp32 ulp of expf is 1e-3 m
+    rep["post_self_dev"] = float((np.abs(det_gpu - det_self) / np.maximum(1.0, np.abs(det_self))).max()) if det_self.size else 0.0
     assert rep["post_self_dev"] <= 2e-5, (label, rep)
     # 4./5. against the reference detections
     det_ref, counts_ref, info_r = O.postprocess(ref["cls"], ref["box"], ref["dir"], m, anchors, class_masks, lim, mode, detail=True, nms_fn=nms_fn)

@@ -191,7 +191,8 @@ def test_backbone_small(norm, fw, synth):
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("force", ["g1x1", "wres", "wino tw8", "wino tw4", "wino tw8 w1x4 bx1 kc4", "wino tw8 w2x4", "k3s1 tw16 w1x4 t4x4", "k3s1 tw4 w2x2 t2x2", "k3s1 tw8 w2x2 t4x5"])
+@pytest.mark.parametrize("force", ["g1x1", "wres", "wino tw8", "wino tw4", "wino tw8 w1x4 bx1 kc4", "wino tw8 w2x4", "wino4 tw4 bx2", "wino4 tw8 bx1", "wino4 tw8 bx2",
+                                   "k3s1 tw16 w1x4 t4x4", "k3s1 tw4 w2x2 t2x2", "k3s1 tw8 w2x2 t4x5"])
 def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
     """Every tiling family (Winograd F(2x2,3x3) and direct, exact and masked-edge shapes) must give the
     same network output, whatever the autotuner would pick."""
