@@ -1053,12 +1053,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) wino_mfm
 #define W4_A100(h) W4_A10(h##0), W4_A10(h##1), W4_A10(h##2), W4_A10(h##3), W4_A10(h##4), W4_A10(h##5), W4_A10(h##6), W4_A10(h##7), W4_A10(h##8), W4_A10(h##9)
 #define W4_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W4_A10(1), W4_A10(2), W4_A10(3), W4_A10(4), W4_A10(5), W4_A10(6), W4_A10(7), W4_A10(8), W4_A10(9), \
                  W4_A100(1), W4_A10(20), W4_A10(21), W4_A10(22), W4_A10(23), W4_A10(24), "a250", "a251", "a252", "a253", "a254", "a255"
-template <int R>
-__device__ __forceinline__ float w4_acc_read()
+// the 16 Winograd positions of (M-tile I, accumulator row R) in ONE statement: hipcc pads every asm boundary with an s_nop
+// before a VALU may touch its outputs -- one pad per 16 reads instead of one per read
+template <int I, int R>
+__device__ __forceinline__ void w4_acc_read16(float (&v)[16])
 {
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(R) : W4_AGPRS);
-    return v;
+    asm volatile("v_accvgpr_read_b32 %0, a%c16\n\tv_accvgpr_read_b32 %1, a%c17\n\tv_accvgpr_read_b32 %2, a%c18\n\tv_accvgpr_read_b32 %3, a%c19\n\t"
+                 "v_accvgpr_read_b32 %4, a%c20\n\tv_accvgpr_read_b32 %5, a%c21\n\tv_accvgpr_read_b32 %6, a%c22\n\tv_accvgpr_read_b32 %7, a%c23\n\t"
+                 "v_accvgpr_read_b32 %8, a%c24\n\tv_accvgpr_read_b32 %9, a%c25\n\tv_accvgpr_read_b32 %10, a%c26\n\tv_accvgpr_read_b32 %11, a%c27\n\t"
+                 "v_accvgpr_read_b32 %12, a%c28\n\tv_accvgpr_read_b32 %13, a%c29\n\tv_accvgpr_read_b32 %14, a%c30\n\tv_accvgpr_read_b32 %15, a%c31"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), "=v"(v[9]),
+                   "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15])
+                 : "i"((0 * 4 + I) * 4 + R), "i"((1 * 4 + I) * 4 + R), "i"((2 * 4 + I) * 4 + R), "i"((3 * 4 + I) * 4 + R), "i"((4 * 4 + I) * 4 + R),
+                   "i"((5 * 4 + I) * 4 + R), "i"((6 * 4 + I) * 4 + R), "i"((7 * 4 + I) * 4 + R), "i"((8 * 4 + I) * 4 + R), "i"((9 * 4 + I) * 4 + R),
+                   "i"((10 * 4 + I) * 4 + R), "i"((11 * 4 + I) * 4 + R), "i"((12 * 4 + I) * 4 + R), "i"((13 * 4 + I) * 4 + R), "i"((14 * 4 + I) * 4 + R),
+                   "i"((15 * 4 + I) * 4 + R)
+                 : W4_AGPRS);
 }
 
 #if defined(PP_W4_DIAG) && (PP_W4_DIAG & 32)
@@ -1302,7 +1312,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     vnext = W4_ROWPASS(tq[0], 0);
 
 #if PP_WINO_STAMP
-    unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0;
+    unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0, sum_p1_ = 0, sum_p2_ = 0;
 #endif
     int buf = 0;                 // ring slot of the chunk being multiplied
     bool pending = false;        // statistics of the previous tile wait in `red` for their cross-wave reduction
@@ -1451,59 +1461,117 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         const __amdgpu_buffer_rsrc_t rres_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres ? gres : gout), 0, gres ? frame_bytes : 0u, 0x00020000);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const unsigned pixb = (unsigned)(((size_t)opy * p.Wout + opx) * 4);
-        // all residual rows are requested up front (buffer descriptor: lanes without a pixel / row and layers without a
-        // residual get zero records), so one memory latency is exposed per tile, not one per M-tile
-        unsigned off0[MT][4], off1[MT][4];
-        f32x2 r0[MT][4], r1[MT][4];
+        // Two halves (M-tiles 0-1, then 2-3), each in two phases.  Phase 1: request the half's residual rows (buffer descriptor:
+        // lanes without a pixel / row and layers without a residual get zero records), then the output transform of its 32
+        // (row, tile) pairs into registers -- no memory access, the residual rows land meanwhile.  Phase 2: ONE wait, then
+        // residual add, stores, statistics.  Loads and stores share vmcnt and may complete out of order with each other, so
+        // hipcc waits with vmcnt(0) for a load once a store is in flight: a residual add between two stores would wait for
+        // every store issued so far (~1 k cycles each).  Here the only such wait (second half) has a whole phase 1 behind the
+        // first half's stores.  The live state of the chunk pipeline (~130 VGPRs) leaves room for one half at a time.
+        // X4 (maps whose width is a multiple of 4): the tile's epilogue is bound by the CU's store ISSUE rate -- four waves x 32
+        // dwordx2 stores of 4 x 128-byte segments each took ~11 k cycles per tile (stamps).  Neighbouring lanes (tiles x, x+1)
+        // swap half their 2x2 outputs over DPP so that the even lane owns row y and the odd lane row y+1 of the pair's 4
+        // pixels: one dwordx4 store (and one dwordx4 residual load) per lane and row instead of two dwordx2.
+        const int par = m & 1;
+        auto epilogue_half = [&](auto HALF, auto X4) {
+            constexpr int h = decltype(HALF)::value;
+            constexpr bool x4 = decltype(X4)::value;
+            unsigned off0[2][4], off1[2][4];
+            f32x2 r0[2][4], r1[2][4];
+            f32x4 rq[2][4];
+            float y[2][4][4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = co0 + i * 16 + kq * 4 + r;
-                const bool ok = pix_ok && row < p.Cout;
-                const unsigned o = (unsigned)((size_t)row * out_plane * 4) + pixb;
-                off0[i][r] = ok ? o : 0xFFFFFFFFu;
-                off1[i][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
-                r0[i][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off0[i][r], 0, 0));
-                r1[i][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off1[i][r], 0, 0));
-            }
-        pp_steps<0, MT>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            float ssum[4], ssq[4];
-            pp_steps<0, 4>([&](auto R) {
-                constexpr int r = decltype(R)::value;
-                float t0[4], t1[4];
-                pp_steps<0, 4>([&](auto A_) {
-                    constexpr int a_ = decltype(A_)::value;
-                    const float m0 = w4_acc_read<((a_ * 4 + 0) * 4 + i) * 4 + r>(), m1 = w4_acc_read<((a_ * 4 + 1) * 4 + i) * 4 + r>(),
-                                m2 = w4_acc_read<((a_ * 4 + 2) * 4 + i) * 4 + r>(), m3 = w4_acc_read<((a_ * 4 + 3) * 4 + i) * 4 + r>();
-                    t0[a_] = m0 + m1 + m2;
-                    t1[a_] = m1 - m2 - m3;
-                });
-                float y00 = t0[0] + t0[1] + t0[2], y01 = t1[0] + t1[1] + t1[2];
-                float y10 = t0[1] - t0[2] - t0[3], y11 = t1[1] - t1[2] - t1[3];
-                y00 += r0[i][r][0]; y01 += r0[i][r][1];
-                y10 += r1[i][r][0]; y11 += r1[i][r][1];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y00, y01}), rout, off0[i][r], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y10, y11}), rout, off1[i][r], 0, 0);
-                const bool ok0 = off0[i][r] != 0xFFFFFFFFu, ok1 = off1[i][r] != 0xFFFFFFFFu;
-                float s_ = y00 + y01, q_ = y00 * y00 + y01 * y01; // same summation order as wino_mfma: row y, then row y+1
-                if (ok1) { s_ += y10; q_ += y10 * y10; s_ += y11; q_ += y11 * y11; }
-                ssum[r] = ok0 ? s_ : 0.f;
-                ssq[r] = ok0 ? q_ : 0.f;
-            });
-            if (p.stat_acc) {
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
-                    if (m == 0) {
-                        const int lr = i * 16 + kq * 4 + r;
-                        red[(wn * C::BM + lr) * 2] = s;
-                        red[(wn * C::BM + lr) * 2 + 1] = q;
+                    const int row = co0 + (h * 2 + ii) * 16 + kq * 4 + r;
+                    const bool ok = pix_ok && row < p.Cout;
+                    const unsigned o = (unsigned)((size_t)row * out_plane * 4) + pixb;
+                    if constexpr (x4) {
+                        // even lane: row y at its own pixels; odd lane: row y+1 starting at the even partner's pixels
+                        const bool okq = ok && (par == 0 || two_y);
+                        off0[ii][r] = okq ? (par ? o + (unsigned)p.Wout * 4u - 8u : o) : 0xFFFFFFFFu;
+                        rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0));
+                    } else {
+                        off0[ii][r] = ok ? o : 0xFFFFFFFFu;
+                        off1[ii][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
+                        r0[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off0[ii][r], 0, 0));
+                        r1[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off1[ii][r], 0, 0));
+                    }
+                }
+#if PP_WINO_STAMP
+            unsigned long long sh0_ = 0, sh1_ = 0, sh2_ = 0;
+            WN_STAMP(sh0_)
+#endif
+            pp_steps<0, 2>([&](auto II) {
+                constexpr int ii = decltype(II)::value, i = h * 2 + ii;
+                pp_steps<0, 4>([&](auto R) {
+                    constexpr int r = decltype(R)::value;
+                    float mm[16], t0[4], t1[4];
+                    w4_acc_read16<i, r>(mm);
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_) {
+                        t0[a_] = mm[a_ * 4 + 0] + mm[a_ * 4 + 1] + mm[a_ * 4 + 2];
+                        t1[a_] = mm[a_ * 4 + 1] - mm[a_ * 4 + 2] - mm[a_ * 4 + 3];
+                    }
+                    y[ii][r][0] = t0[0] + t0[1] + t0[2]; y[ii][r][1] = t1[0] + t1[1] + t1[2];
+                    y[ii][r][2] = t0[1] - t0[2] - t0[3]; y[ii][r][3] = t1[1] - t1[2] - t1[3];
+                });
+            });
+            WN_STAMP(sh1_)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                float ssum[4], ssq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (x4) {
+                        const float s0 = par ? y[ii][r][0] : y[ii][r][2], s1 = par ? y[ii][r][1] : y[ii][r][3]; // what the partner needs of mine
+                        const float g0 = dpp_f32<0xB1>(s0), g1 = dpp_f32<0xB1>(s1);                               // quad_perm [1,0,3,2]: lane ^ 1
+                        f32x4 v;
+                        v[0] = par ? g0 : y[ii][r][0]; v[1] = par ? g1 : y[ii][r][1];
+                        v[2] = par ? y[ii][r][2] : g0; v[3] = par ? y[ii][r][3] : g1;
+                        v += rq[ii][r];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0u, 0, 0)), v), rout, off0[ii][r], 0, 0);
+                        const bool okq = off0[ii][r] != 0xFFFFFFFFu;
+                        const float s_ = ((v[0] + v[1]) + v[2]) + v[3], q_ = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
+                        ssum[r] = okq ? s_ : 0.f;
+                        ssq[r] = okq ? q_ : 0.f;
+                    } else {
+                        const float y00 = y[ii][r][0] + r0[ii][r][0], y01 = y[ii][r][1] + r0[ii][r][1];
+                        const float y10 = y[ii][r][2] + r1[ii][r][0], y11 = y[ii][r][3] + r1[ii][r][1];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y00, y01}), rout, off0[ii][r], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y10, y11}), rout, off1[ii][r], 0, 0);
+                        const bool ok0 = off0[ii][r] != 0xFFFFFFFFu, ok1 = off1[ii][r] != 0xFFFFFFFFu;
+                        float s_ = y00 + y01, q_ = y00 * y00 + y01 * y01; // same summation order as wino_mfma: row y, then row y+1
+                        if (ok1) { s_ += y10; q_ += y10 * y10; s_ += y11; q_ += y11 * y11; }
+                        ssum[r] = ok0 ? s_ : 0.f;
+                        ssq[r] = ok0 ? q_ : 0.f;
+                    }
+                }
+                if (p.stat_acc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
+                        if (m == 0) {
+                            const int lr = (h * 2 + ii) * 16 + kq * 4 + r;
+                            red[(wn * C::BM + lr) * 2] = s;
+                            red[(wn * C::BM + lr) * 2 + 1] = q;
+                        }
                     }
                 }
             }
-        });
+#if PP_WINO_STAMP
+            WN_STAMP(sh2_)
+            sum_p1_ += sh1_ - sh0_; sum_p2_ += sh2_ - sh1_;
+#endif
+        };
+        if ((p.Wout & 3) == 0) {
+            epilogue_half(std::integral_constant<int, 0>{}, std::true_type{});
+            epilogue_half(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            epilogue_half(std::integral_constant<int, 0>{}, std::false_type{});
+            epilogue_half(std::integral_constant<int, 1>{}, std::false_type{});
+        }
         if (p.stat_acc) {
             pending = true;
             pend_dst = p.stat_acc + fz * p.stat_fs + ((size_t)(blockIdx.x % NREP) * p.stat_C + co0) * 2;
@@ -1517,6 +1585,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     if (tid == 0 && p.dbg_buf) {
         atomicAdd(&p.dbg_buf[0], sum_pre_); atomicAdd(&p.dbg_buf[1], sum_steps_); atomicAdd(&p.dbg_buf[2], sum_bar_);
         atomicAdd(&p.dbg_buf[3], sum_epi_); atomicAdd(&p.dbg_buf[4], n_chunks_); atomicAdd(&p.dbg_buf[5], n_tiles_);
+        atomicAdd(&p.dbg_buf[6], sum_p1_); atomicAdd(&p.dbg_buf[7], sum_p2_);
     }
 #endif
     if (pending) {

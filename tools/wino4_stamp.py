@@ -25,9 +25,9 @@ lib.pp_debug_set_stamp_buffer(ctypes.c_void_p(dbuf.data_ptr()))
 for _ in range(3):
     eng.infer_batch(clouds)
 torch.cuda.synchronize()
-pre, steps, bar, epi, nch, nt = [int(v) for v in dbuf.cpu().numpy()][:6]
+pre, steps, bar, epi, nch, nt, p1, p2 = [int(v) for v in dbuf.cpu().numpy()][:8]
 tot = pre + steps + bar + epi
 print(f"{os.environ['PP_FORCE_VARIANT']}: chunks {nch} tiles {nt} ({nch / nt:.1f} chunks per tile)")
 print(f"cycles per chunk: top (wait for loads, normalise, advance) {pre / nch:.0f}   32 steps {steps / nch:.0f} (matrix pipe floor 4096)   barrier {bar / nch:.0f}")
-print(f"cycles per tile: epilogue {epi / nt:.0f}   whole tile {tot / nt:.0f}")
+print(f"cycles per tile: epilogue {epi / nt:.0f} (output transform {p1 / nt:.0f}, residual add + stores + statistics {p2 / nt:.0f}, rest {(epi - p1 - p2) / nt:.0f})   whole tile {tot / nt:.0f}")
 print(f"shares: top {pre / tot:.3f}  steps {steps / tot:.3f}  barrier {bar / tot:.3f}  epilogue {epi / tot:.3f}")
