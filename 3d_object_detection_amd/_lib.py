@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpp_hip.so")
-PP_MAX_CLASSES = 8
+PP_MAX_CLASSES = 12
 
 c_f = ctypes.c_float
 c_i32 = ctypes.c_int32

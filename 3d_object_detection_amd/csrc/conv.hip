@@ -113,8 +113,8 @@ struct ConvP {
     const float* bias;
     float* out_box;
     float* out_dir;
-    int n_cls, n_box; // 9, 63 (dir = rest up to n_rows)
-    int n_rows;       // 90
+    int n_cls, n_box; // na, 7 na (dir = rest up to n_rows) for na anchors per location (reference: 9, 63)
+    int n_rows;       // 10 na (reference: 90)
     int dbg;          // diagnostics only (PP_CONV_DBG): 1 = skip staging after chunk 0, 4 = skip epilogue
     // batch: blockIdx.z = frame; strides in elements between consecutive frames
     size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
@@ -1123,7 +1123,7 @@ template <int TWT, int BTX, int KC, int ROOFLINE = 0>
 __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 {
     using C = Wino4Cfg<TWT, BTX, KC>;
-    constexpr int MT = 4, WN = 4;
+    constexpr int WN = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* il = smem;                               // [3][KC][CS]
     float* wl = il + C::NSTAGE * C::LDS_IN;         // [3][16][KC][64]
@@ -1331,9 +1331,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         auto chunk_body = [&](auto FIRST, int ch) {
             constexpr bool first_ = decltype(FIRST)::value;
             const int nbuf = buf == 2 ? 0 : buf + 1, wbuf = buf == 0 ? 2 : buf - 1; // (buf+1)%3, (buf+2)%3
-            const float* ib = il + buf * C::LDS_IN;
             const float* wb = wl + buf * C::LDS_W;
-            const float* ibn = il + nbuf * C::LDS_IN;
             const float* wbn = wl + nbuf * C::LDS_W;
             float* ibw = il + wbuf * C::LDS_IN;
             float* wbw = wl + wbuf * C::LDS_W;
@@ -2419,11 +2417,12 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false)
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true)
 {
     const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
     if (kind == 2) {
-        if (g1ok) { menu.push_back(make_g1<6, 4, EPI_HEAD>()); menu.push_back(make_g1<3, 4, EPI_HEAD>()); }
+        // the persistent 1x1 GEMM's head epilogue (head_tile_row) is laid out for the reference's 9 anchors per location
+        if (g1ok && head9) { menu.push_back(make_g1<6, 4, EPI_HEAD>()); menu.push_back(make_g1<3, 4, EPI_HEAD>()); }
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 5, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 1, 4, 6, 2, 1, 16, EPI_HEAD>());
         menu.push_back(make_variant<1, 1, 16, 2, 2, 3, 5, 1, 16, EPI_HEAD>());
@@ -2475,10 +2474,10 @@ bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
-Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
+Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout, bool head9 = true)
 {
     std::vector<Variant> menu;
-    layer_menu(kind, stride, up, menu);
+    layer_menu(kind, stride, up, menu, 0, false, head9);
     double best = 1e30;
     Variant bv = menu[0];
     for (const Variant& v : menu) {
@@ -2491,7 +2490,7 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
     const char* prefer = (kind == 0 && stride == 1) ? "wino tw8 w1x4 bx1 kc8"
                          : (kind == 1 && up == 2)   ? "g1x1 m4 n4 e1"
                          : (kind == 1 && up == 4)   ? "g1x1 m4 n4 e2"
-                         : (kind == 2)              ? "g1x1 m6 n4 e3"
+                         : (kind == 2 && head9)     ? "g1x1 m6 n4 e3"
                                                     : nullptr;
     if (prefer)
         for (const Variant& v : menu)
@@ -2508,6 +2507,10 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout)
 // (natural order: cls 0..8, box 9 + 7a + k, dir 72 + 2a + k, head rows 90..95 are zero).  With the natural order
 // the 81 box/dir rows cost 4 scalar stores each per lane -- 333 scattered store instructions per 64 pixels, whose
 // completion the next item's first loads had to wait for (vmcnt is in order): 38 % of the head's wave time.
+// GEMM rows of the head for na anchors per location: cls na | box 7 na | dir 2 na, padded to whole 96-row blocks (the
+// head tilings are 96 rows tall; the reference's 9 anchors give 90 -> 96)
+static inline int head_rows(int na) { return ((10 * na + 95) / 96) * 96; }
+
 static inline int head_tile_row(int t)
 {
     const int g = t >> 2, r = t & 3;
@@ -2544,10 +2547,11 @@ int pack_layer(pp_ctx* ctx, Layer& L)
             for (int co = 0; co < L.cout; ++co)
                 for (int d = 0; d < u2; ++d) rowsW[((size_t)co * u2 + d) * L.cin + ci] = s[((size_t)ci * L.cout + co) * u2 + d];
     } else {
-        rows = 96;
-        rowsW.assign((size_t)96 * L.cin, 0.f);
+        const int na = ctx->cfg.num_anchor_per_loc;
+        rows = head_rows(na);
+        rowsW.assign((size_t)rows * L.cin, 0.f);
         const char* names[3] = {"heads.conv_cls.weight", "heads.conv_box.weight", "heads.conv_dir.weight"};
-        const int cnt[3] = {9, 63, 18};
+        const int cnt[3] = {na, 7 * na, 2 * na};
         int r0 = 0;
         for (int h = 0; h < 3; ++h) {
             auto w = ctx->host_w.find(names[h]);
@@ -2670,15 +2674,15 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.stat_acc = stat_acc; p.stat_C = stat_C;
     p.dbg_buf = g_stamp_buf;
     p.bias = (L.kind == 2 && L.var.wino == 3) ? net->head_bias_perm : net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
-    p.n_cls = 9; p.n_box = 63; p.n_rows = 90;
+    { const int na = ctx->cfg.num_anchor_per_loc; p.n_cls = na; p.n_box = 7 * na; p.n_rows = 10 * na; }
     { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
     {   // frame strides of a batched launch (every per-frame tensor is stored [B][...])
         const size_t hw = (size_t)Hout * Wout;
         p.in_fs = in_fs ? in_fs : (size_t)L.cin * Hin * Win;
-        p.out_fs = out_fs ? out_fs : (L.kind == 2 ? (size_t)9 * hw : (size_t)L.rows * hw);
+        p.out_fs = out_fs ? out_fs : (L.kind == 2 ? (size_t)p.n_cls * hw : (size_t)L.rows * hw);
         p.res_fs = p.out_fs;
-        p.box_fs = (size_t)63 * hw;
-        p.dir_fs = (size_t)18 * hw;
+        p.box_fs = (size_t)p.n_box * hw;
+        p.dir_fs = (size_t)2 * p.n_cls * hw;
         p.pre_fs = pre.fs;
         p.stat_fs = STAT_FS;
         p.pmap = pmap; p.feat = feat;
@@ -2811,12 +2815,12 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
     std::vector<Variant> menu;
-    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0);
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9);
     // the key carries the library version and the menu size (an entry of another build's menu is not trusted), not the
     // device index: the GPUs of a node are identical, and ranks must be able to share rank 0's table
     snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
              ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
-    const int rows = (L.kind == 2) ? 96 : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
+    const int rows = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
             if (variant_ok(v, rows) && !(v.wino == 4 && (Wout & 1)) && strstr(v.name, force)) { L.var = v; return 0; }
@@ -2922,7 +2926,7 @@ int pp_net_create(pp_ctx* ctx)
     PP_HIP(hipMalloc((void**)&net->aff, (size_t)ctx->max_batch * 640 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->bn_scale, (size_t)24 * 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->bn_shift, (size_t)24 * 320 * sizeof(float)));
-    PP_HIP(hipMalloc((void**)&net->head_bias, 96 * sizeof(float)));
+    PP_HIP(hipMalloc((void**)&net->head_bias, (size_t)head_rows(ctx->cfg.num_anchor_per_loc) * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->head_bias_perm, 96 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->ones, 320 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&net->zeros, 320 * sizeof(float)));
@@ -2952,7 +2956,8 @@ int pp_net_create(pp_ctx* ctx)
         net->layers.push_back(Layer{key, 1, c, (b == 0) ? 64 : 128, 1, up, b, pick_variant(1, 1, up, ((b == 0) ? 64 : 128) * up * up, H >> b, W >> b)});
         cin = c;
     }
-    net->layers.push_back(Layer{"heads", 2, 320, 90, 1, 1, 0, pick_variant(2, 1, 1, 96, H, W)});
+    net->layers.push_back(Layer{"heads", 2, 320, 10 * ctx->cfg.num_anchor_per_loc, 1, 1, 0,
+                                pick_variant(2, 1, 1, head_rows(ctx->cfg.num_anchor_per_loc), H, W, ctx->cfg.num_anchor_per_loc == 9)});
     for (Layer& L : net->layers)
         PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
     return 0;
@@ -3004,9 +3009,11 @@ static inline int site_block(int b, int k) { return 8 * b + k; }
 int pp_net_commit(pp_ctx* ctx)
 {
     pp_net* net = (pp_net*)ctx->net;
-    float hb[96] = {0};
+    const int na = ctx->cfg.num_anchor_per_loc;
+    std::vector<float> hbv((size_t)head_rows(na), 0.f);
+    float* hb = hbv.data();
     const char* names[3] = {"heads.conv_cls.bias", "heads.conv_box.bias", "heads.conv_dir.bias"};
-    const int cnt[3] = {9, 63, 18};
+    const int cnt[3] = {na, 7 * na, 2 * na};
     int r0 = 0;
     for (int h = 0; h < 3; ++h) {
         auto w = ctx->host_w.find(names[h]);
@@ -3015,8 +3022,8 @@ int pp_net_commit(pp_ctx* ctx)
         memcpy(hb + r0, w->second.data.data(), sizeof(float) * cnt[h]);
         r0 += cnt[h];
     }
-    PP_HIP(hipMemcpy(net->head_bias, hb, sizeof(hb), hipMemcpyHostToDevice));
-    {
+    PP_HIP(hipMemcpy(net->head_bias, hb, hbv.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (na == 9) {
         float hp[96];
         for (int t = 0; t < 96; ++t) hp[t] = head_tile_row(t) >= 0 ? hb[head_tile_row(t)] : 0.f;
         PP_HIP(hipMemcpy(net->head_bias_perm, hp, sizeof(hp), hipMemcpyHostToDevice));

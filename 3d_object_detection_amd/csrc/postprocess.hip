@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, i
 {
     nms_mask_body(blockIdx.z, nbox, nstride, nsel_p, nsel_stride, K, cb, thr, rotate, maskT);
 }
-__global__ void __launch_bounds__(512) nms_reduce(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
+__global__ void __launch_bounds__(64 * PP_MAX_CLASSES) nms_reduce(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
                                                   const float* __restrict__ boxes, const int32_t* __restrict__ dirl, int32_t* __restrict__ counters,
                                                   int K, int cb, int32_t* __restrict__ keep_ws, float* __restrict__ det, int32_t* __restrict__ det_count)
 {
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(64) nms_mask_b(const pp_post_frame* __restrict
     const pp_post_frame F = tab[fr];
     nms_mask_body(c, F.nbox, 6, F.counters + 3, 8, K, cb, thr, rotate, F.nmask);
 }
-__global__ void __launch_bounds__(512) nms_reduce_b(const pp_post_frame* __restrict__ tab, pp_config cfg, int K, int cb, float* __restrict__ det,
+__global__ void __launch_bounds__(64 * PP_MAX_CLASSES) nms_reduce_b(const pp_post_frame* __restrict__ tab, pp_config cfg, int K, int cb, float* __restrict__ det,
                                                     size_t det_fs, int32_t* __restrict__ det_count, int cnt_fs)
 {
     const pp_post_frame F = tab[blockIdx.z];
@@ -714,7 +714,7 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
                        ctx->anchors, nms_mode, P->sel, P->boxes, P->nbox, P->dirl);
     hipLaunchKernelGGL(nms_mask, dim3(P->cb, P->cb, n), dim3(64), 0, stream, P->nbox, 6, P->counters + 3, 8, P->K, P->cb,
                        c.nms_iou_threshold, nms_mode, P->nmask);
-    hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(512), 0, stream, c, P->nmask, P->sel, P->boxes, P->dirl, P->counters, P->K, P->cb,
+    hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64 * PP_MAX_CLASSES), 0, stream, c, P->nmask, P->sel, P->boxes, P->dirl, P->counters, P->K, P->cb,
                        P->dirl + (size_t)n * P->K, det, det_count);
     PP_HIP(hipGetLastError());
     return 0;
@@ -745,7 +745,7 @@ int pp_postprocess_group(pp_ctx* ctx, int b0, int g, float* det, int32_t* det_co
     hipLaunchKernelGGL(post_gather_b, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n, g), dim3(256), 0, stream, tab, P->cand_cap, P->thr_bits, P->bin_shift);
     hipLaunchKernelGGL(post_topk_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, c, P->cand_cap, P->K, ctx->anchors, nms_mode);
     hipLaunchKernelGGL(nms_mask_b, dim3(P->cb, P->cb, n * g), dim3(64), 0, stream, tab, n, P->K, P->cb, c.nms_iou_threshold, nms_mode);
-    hipLaunchKernelGGL(nms_reduce_b, dim3(1, 1, g), dim3(512), 0, stream, tab, c, P->K, P->cb, det + (size_t)b0 * det_fs, det_fs,
+    hipLaunchKernelGGL(nms_reduce_b, dim3(1, 1, g), dim3(64 * PP_MAX_CLASSES), 0, stream, tab, c, P->K, P->cb, det + (size_t)b0 * det_fs, det_fs,
                        det_count + (size_t)b0 * PP_DET_COUNT_STRIDE, (int)PP_DET_COUNT_STRIDE);
     PP_HIP(hipGetLastError());
     return 0;

@@ -27,6 +27,20 @@ CLASS_TABLE = {
 NUM_ANCHOR_PER_LOC = 9
 
 
+def class_table_of(config):
+    """(names, table) of the anchor classes.  The reference ignores the config and hard-codes three classes
+    (anchor_assigner.py:222-245); a config carrying `class_table` (build-side extension, e.g. the 10-class nuScenes
+    table of configs/nuscene_10class.json: name -> {sizes [[l,w,h]..], rotations [..]}) selects its own, in
+    `detect_class` order when that lists the same names."""
+    tab = config.get("class_table")
+    if not tab:
+        return list(DETECT_CLASSES), CLASS_TABLE
+    names = [n for n in config.get("detect_class", []) if n in tab]
+    if len(names) != len(tab):
+        names = list(tab.keys())
+    return names, {n: dict(tab[n]) for n in names}
+
+
 def snap_geometry(config):
     """VoxelGenerator.__init__ arithmetic (voxel_generator.py:6-26): snap the range to whole cells."""
     dr = np.array(config["detection_range"], dtype=F32)
@@ -42,7 +56,7 @@ def _limit_period(val, offset=0.5, period=np.pi):
     return val - np.floor(val / period + offset) * period
 
 
-def build_anchor_tables(offset, range_diff, grid_size, voxel_size):
+def build_anchor_tables(offset, range_diff, grid_size, voxel_size, names=None, table=None):
     """Host mirror of AnchorAssigner.__init__/.generate (anchor_assigner.py:247-320) plus
     rbbox2d_to_near_bbox / get_anchor_coor (box_np_ops.py:308-320,288-305).  The reference
     hard-codes a 400x400 feature map; here it is grid/2 (the same for eight_20cm)."""
@@ -51,9 +65,11 @@ def build_anchor_tables(offset, range_diff, grid_size, voxel_size):
     centre0 = offset + strides / 2
     xs = np.arange(int(fmap[0]), dtype=F32) * strides[0] + centre0[0]
     ys = np.arange(int(fmap[1]), dtype=F32) * strides[1] + centre0[1]
+    names = list(DETECT_CLASSES) if names is None else names
+    table = CLASS_TABLE if table is None else table
     tables, class_masks, start = [], {}, 0
-    for name in DETECT_CLASSES:
-        t = CLASS_TABLE[name]
+    for name in names:
+        t = table[name]
         parts = []
         for size in t["sizes"]:
             zc = (np.arange(1, dtype=F32) * strides[2] + size[2] / 2)[0]
@@ -125,9 +141,14 @@ class Engine:
         self.T = int(config["max_num_points"])
         self.F = int(config.get("num_point_features", 4))
         self.device = torch.device("cuda", device_index)
-        self.anchors_np, self.anchors_bv, self.rects_np, self.class_masks = build_anchor_tables(offset, range_diff, grid, vs)
+        self.class_names, self.class_table = class_table_of(config)
+        self.anchors_np, self.anchors_bv, self.rects_np, self.class_masks = build_anchor_tables(offset, range_diff, grid, vs, self.class_names,
+                                                                                                 self.class_table)
         self.A = self.anchors_np.shape[0]
         self.H, self.W = int(grid[0]) // 2, int(grid[1]) // 2
+        self.num_anchor_per_loc = self.A // (self.H * self.W)
+        if len(self.class_masks) > _lib.PP_MAX_CLASSES:
+            raise ValueError(f"{len(self.class_masks)} anchor classes: the library is built for at most {_lib.PP_MAX_CLASSES}")
         c = _lib.PPConfig()
         for i in range(3):
             c.voxel_size[i] = float(vs[i])
@@ -135,7 +156,7 @@ class Engine:
             c.grid_size[i] = int(grid[i])
         c.max_voxels, c.max_num_points, c.num_point_features = self.max_voxels, self.T, self.F
         c.max_points = int(max_points or config.get("max_points", 1 << 18))
-        c.num_anchor_per_loc = NUM_ANCHOR_PER_LOC
+        c.num_anchor_per_loc = self.num_anchor_per_loc
         c.num_classes = len(self.class_masks)
         for i, (s, e) in enumerate(self.class_masks.values()):
             c.class_begin[i], c.class_end[i] = s, e

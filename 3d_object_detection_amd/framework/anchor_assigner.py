@@ -3,20 +3,22 @@ Target assignment (`assign`, :337-425) is training-only and out of scope."""
 import numpy as np
 import torch
 
-from ..engine import CLASS_TABLE, DETECT_CLASSES, engine_for
+from ..engine import class_table_of, engine_for
 
 
 class AnchorAssigner:
     def __init__(self, config):
-        # the reference overwrites detect_class and adds the per-class dicts (:222-245)
-        config['detect_class'] = list(DETECT_CLASSES)
+        # the reference overwrites detect_class and adds the per-class dicts (:222-245); a config with its own
+        # `class_table` (build-side extension, engine.class_table_of) keeps its classes
+        names, table = class_table_of(config)
+        config['detect_class'] = list(names)
         self.detect_class = config['detect_class']
         fm = [int(config['grid_size'][0]) // 2, int(config['grid_size'][1]) // 2, 1]
-        for name in DETECT_CLASSES:
-            t = CLASS_TABLE[name]
+        for name in names:
+            t = table[name]
             config[name] = dict(sizes=[list(s) for s in t['sizes']], rotations=list(t['rotations']),
                                 feature_map_size=[list(fm) for _ in t['sizes']],
-                                matched_threshold=t['matched_threshold'], unmatched_threshold=t['unmatched_threshold'])
+                                matched_threshold=t.get('matched_threshold', 0.6), unmatched_threshold=t.get('unmatched_threshold', 0.45))
         self.anchor_offsets = config['detection_offset']
         self.grid_size = config['grid_size']
         self.box_code_size = config['box_code_size']
@@ -27,9 +29,9 @@ class AnchorAssigner:
         self.anchors_coors = eng.rects_np
         self.class_masks = eng.class_masks
         self.matched_threshold = np.concatenate(
-            [np.full(e - s, CLASS_TABLE[n]['matched_threshold'], np.float32) for n, (s, e) in self.class_masks.items()])
+            [np.full(e - s, table[n].get('matched_threshold', 0.6), np.float32) for n, (s, e) in self.class_masks.items()])
         self.unmatched_threshold = np.concatenate(
-            [np.full(e - s, CLASS_TABLE[n]['unmatched_threshold'], np.float32) for n, (s, e) in self.class_masks.items()])
+            [np.full(e - s, table[n].get('unmatched_threshold', 0.45), np.float32) for n, (s, e) in self.class_masks.items()])
 
     def create_mask_device(self, coors, num):
         """coors i32[>=P,3] cuda, num i32[1] cuda -> bool[A] cuda."""

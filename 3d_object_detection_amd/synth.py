@@ -16,6 +16,7 @@ _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
 # name -> (beams, elev_lo_deg, elev_hi_deg, n_points, sensor_height)
 CLOUD_SHAPES = {
+    "nuscene_10class": (32, -30.0, 10.0, 34000, 1.8),
     "eight_20cm": (64, -24.8, 2.0, 20000, 1.7),
     "ntusl_10cm": (64, -24.8, 2.0, 60000, 1.7),
     "nuscene": (32, -30.0, 10.0, 34000, 1.8),
@@ -87,7 +88,7 @@ def lidar_cloud(shape="eight_20cm", seed=1000, n_points=None, max_range=75.0):
     return np.ascontiguousarray(out)
 
 
-def seeded_state_dict(seed=0, norm="instance", cls_bias=None):
+def seeded_state_dict(seed=0, norm="instance", cls_bias=None, num_anchor_per_loc=9):
     """Random-init weights with the reference's state_dict key names/shapes
     (networks/pointpillars8_shared.py:346-357), with
     non-trivial BatchNorm running stats so the PFN padded-slot term and BN folding
@@ -131,7 +132,8 @@ def seeded_state_dict(seed=0, norm="instance", cls_bias=None):
         sd[f"rpn.deconv{di}.0.weight"] = rng.uniform(-bound, bound, (ci, co, k, k)).astype(np.float32)
         bn(f"rpn.deconv{di}.1", co)
     bound = 1.0 / np.sqrt(320.0)
-    for name, co in (("cls", 9), ("box", 63), ("dir", 18)):
+    na = int(num_anchor_per_loc)  # head rows: cls na | box 7 na | dir 2 na (reference: 9 anchors per location)
+    for name, co in (("cls", na), ("box", 7 * na), ("dir", 2 * na)):
         sd[f"heads.conv_{name}.weight"] = rng.uniform(-bound, bound, (co, 320, 1, 1)).astype(np.float32)
         sd[f"heads.conv_{name}.bias"] = rng.uniform(-bound, bound, co).astype(np.float32)
     if cls_bias is not None:  # "trained-like": few anchors pass the 0.05 score threshold

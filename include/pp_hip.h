@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PP_MAX_CLASSES 8
+#define PP_MAX_CLASSES 12 /* class ranges of the anchor table (reference: 3; the build-side nuScenes table: 10) */
 #define PP_E_ARG 1      /* bad argument (null pointer, size out of range) */
 #define PP_E_STATE 2    /* weights / anchors not loaded yet */
 #define PP_E_NAME 3     /* unknown weight name or wrong shape */
@@ -39,8 +39,8 @@ typedef struct pp_config {
     int32_t max_num_points;   /* T */
     int32_t num_point_features; /* F (4) */
     int32_t max_points;       /* capacity of the per-point workspace (N upper bound) */
-    int32_t num_anchor_per_loc; /* 9 */
-    int32_t num_classes;      /* 3 */
+    int32_t num_anchor_per_loc; /* anchors per BEV location = head geometry: cls na, box 7*na, dir 2*na rows (reference: 9) */
+    int32_t num_classes;      /* <= PP_MAX_CLASSES (reference: 3) */
     int32_t class_begin[PP_MAX_CLASSES]; /* anchor index ranges, class_masks of anchor_assigner.py:289 */
     int32_t class_end[PP_MAX_CLASSES];
     double center_limit[6];   /* compared in fp64 like inference.py:105-109 (python floats) */

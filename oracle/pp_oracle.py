@@ -143,17 +143,20 @@ def anchor_cell_rects(anchors_bv, voxel_size, offset, grid_size):
     return c
 
 
-def make_anchors(setup, feature_map_size=None):
+def make_anchors(setup, feature_map_size=None, class_table=None):
     """Anchor table in the reference's order class -> size -> rotation -> x -> y.
     The reference hard-codes a 400x400 map (anchor_assigner.py:227); the oracle
-    derives it as grid/2 (identical for eight_20cm) so the other configs work."""
+    derives it as grid/2 (identical for eight_20cm) so the other configs work.
+    class_table (dict name -> {sizes, rotations}, insertion-ordered) replaces the reference's hard-coded three
+    classes for the build-side 10-class nuScenes config, which has no reference counterpart (parity unpinned there)."""
+    classes = ANCHOR_CLASSES if not class_table else [(n, t["sizes"], t["rotations"]) for n, t in class_table.items()]
     grid = setup["grid_size"]
     if feature_map_size is None:
         feature_map_size = [int(grid[0]) // 2, int(grid[1]) // 2, 1]
     fmap = np.asarray(feature_map_size, dtype=F32)
     strides = setup["range_diff"] / fmap
     tabs, masks, start = [], {}, 0
-    for name, sizes, rots in ANCHOR_CLASSES:
+    for name, sizes, rots in classes:
         parts = [_one_anchor_grid(s, r, fmap, strides, setup["offset"]) for s in sizes for r in rots]
         t = np.concatenate(parts)
         tabs.append(t)

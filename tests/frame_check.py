@@ -32,7 +32,9 @@ def oracle_frame(synth, name, pts, sd, norm="instance", num_anchor_per_loc=9, se
     """voxelise -> mask -> PFN -> scatter -> backbone -> head on the CPU oracle (logits, not detections)."""
     cfg = synth.load_config(name)
     s = setup or O.voxel_setup(cfg)
-    a = anchors or O.make_anchors(s)
+    a = anchors or O.make_anchors(s, class_table=cfg.get("class_table"))
+    if cfg.get("class_table"):
+        num_anchor_per_loc = sum(len(t["sizes"]) * len(t["rotations"]) for t in cfg["class_table"].values())
     v, c, n = C.points_to_voxels(pts, s["voxel_size"], s["offset"], s["grid_size"], cfg["max_voxels"], cfg["max_num_points"])
     mask = C.create_mask(c, s["grid_size"], a["anchors_coors"])
     feat = O.pfn(v, n, c, sd, s)

@@ -37,9 +37,12 @@ def test_config_struct_layout_matches_header():
     c = lib_mod.PPConfig
     # offsets as laid out by a C compiler for the struct in pp_hip.h (natural alignment)
     assert c.voxel_size.offset == 0 and c.offset.offset == 12 and c.grid_size.offset == 24
-    assert c.max_voxels.offset == 36 and c.class_begin.offset == 60 and c.class_end.offset == 92
-    assert c.center_limit.offset == 128 and c.norm_kind.offset == 176
-    assert ctypes.sizeof(c) == 200
+    n = lib_mod.PP_MAX_CLASSES
+    hdr = open(HEADER).read()
+    assert int(re.search(r"#define PP_MAX_CLASSES (\d+)", hdr).group(1)) == n == 12
+    assert c.max_voxels.offset == 36 and c.class_begin.offset == 60 and c.class_end.offset == 60 + 4 * n
+    assert c.center_limit.offset == 160 and c.norm_kind.offset == 208  # 60 + 8n = 156 -> doubles aligned to 160
+    assert ctypes.sizeof(c) == 232
 
 
 def test_no_gpu_no_fallback(synth):
@@ -135,3 +138,23 @@ def test_stateless_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.pp_eval_statistics(None, 0, 2, 2, None, None, None, 0.5, 0.0, 0, out, None, None) != 0
     assert lib.pp_eval_statistics(None, 0, 0, 0, None, None, None, 0.5, 0.0, 0, None, None, None) != 0
     assert lib.pp_eval_statistics(None, 0, 0, 0, None, None, None, 0.5, 0.0, 0, out, None, None) == 0 and list(out) == [0, 0, 0]
+
+
+def test_class_table_from_config(synth):
+    """Build-side 10-class nuScenes table (no reference counterpart): engine mirror == oracle restatement, class ranges
+    contiguous in table order, 20 anchors per location; the shipped 3-class configs keep the reference's hard-coded table."""
+    from oracle import pp_oracle as O
+    eng = load_pkg("engine")
+    cfg = synth.load_config("nuscene_10class")
+    names, table = eng.class_table_of(cfg)
+    assert names == cfg["detect_class"] and len(names) == 10
+    vs, off, grid, rd, _ = eng.snap_geometry(cfg)
+    anchors, bv, rects, masks = eng.build_anchor_tables(off, rd, grid, vs, names, table)
+    a = O.make_anchors(O.voxel_setup(cfg), class_table=cfg["class_table"])
+    assert np.array_equal(anchors, a["anchors"]) and np.array_equal(rects, a["anchors_coors"]) and masks == a["class_masks"]
+    hw = (int(grid[0]) // 2) * (int(grid[1]) // 2)
+    assert anchors.shape[0] == 20 * hw and list(masks) == names
+    assert [e - s for s, e in masks.values()] == [2 * hw] * 10
+    assert eng.class_table_of(synth.load_config("nuscene"))[0] == ["vehicle", "pedestrian", "cyclist"]
+    sd = synth.seeded_state_dict(0, num_anchor_per_loc=20)
+    assert sd["heads.conv_cls.weight"].shape[0] == 20 and sd["heads.conv_box.weight"].shape[0] == 140 and sd["heads.conv_dir.bias"].shape[0] == 40
