@@ -49,6 +49,7 @@ extern "C" int pp_infer_batch(pp_ctx* ctx, const float* const* pts_h, const int3
         if ((rc = pp_stage_mark(ctx, stream, PP_ST_POST))) return rc;
         for (int b0 = 0; b0 < nb; b0 += PP_GROUP) {
             const int g = nb - b0 < PP_GROUP ? nb - b0 : PP_GROUP;
+            if (b0 && (rc = pp_stage_mark(ctx, stream, PP_ST_POST))) return rc;
             if ((rc = pp_postprocess_group(ctx, b0, g, det, det_count, nms_mode, stream))) return rc;
         }
         return pp_stage_mark(ctx, stream, -1);

@@ -32,7 +32,7 @@ __device__ __forceinline__ void pfn_kernel_body(const float* __restrict__ voxels
     const int waves = (gridDim.x * blockDim.x) >> 6;
     for (int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < P; p += waves) {
         const float* v = voxels + (size_t)p * T * 4;
-        const int n = npts[p];
+        const int n = min(npts[p], T); // a count beyond the T slots of the pillar buffer would read the next pillar's rows
         // pass 1: sum of x,y,z over ALL T slots (padded slots are zero), as :32 does
         float s = 0.f;
         for (int j = lane; j < T * 4; j += 64) s += v[j];
@@ -68,23 +68,28 @@ __device__ __forceinline__ void pfn_kernel_body(const float* __restrict__ voxels
 }
 
 __global__ void __launch_bounds__(256) scatter_kernel(const float* __restrict__ feat, const int32_t* __restrict__ coors,
-                                                      const int32_t* __restrict__ num_pillars, int gy, size_t plane,
+                                                      const int32_t* __restrict__ num_pillars, int gx, int gy, size_t plane,
                                                       float* __restrict__ canvas)
 {
     const int lane = threadIdx.x & 63;
     const int P = *num_pillars;
     const int waves = (gridDim.x * blockDim.x) >> 6;
     for (int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < P; p += waves) {
-        size_t cell = (size_t)coors[3 * p] * gy + coors[3 * p + 1];
+        const int cx = coors[3 * p], cy = coors[3 * p + 1];
+        if ((unsigned)cx >= (unsigned)gx || (unsigned)cy >= (unsigned)gy) continue; // a coordinate outside the grid is skipped, never written
+        size_t cell = (size_t)cx * gy + cy;
         canvas[(size_t)lane * plane + cell] = feat[(size_t)p * 64 + lane];
     }
 }
 
-__device__ __forceinline__ void pmap_kernel_body(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy,
+__device__ __forceinline__ void pmap_kernel_body(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gx, int gy,
                                                    int32_t* __restrict__ pmap)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < *num_pillars) pmap[(size_t)coors[3 * p] * gy + coors[3 * p + 1]] = p;
+    if (p < *num_pillars) {
+        const int cx = coors[3 * p], cy = coors[3 * p + 1];
+        if ((unsigned)cx < (unsigned)gx && (unsigned)cy < (unsigned)gy) pmap[(size_t)cx * gy + cy] = p;
+    }
 }
 
 __global__ void __launch_bounds__(256) pfn_kernel(const float* __restrict__ voxels, const int32_t* __restrict__ coors, const int32_t* __restrict__ npts,
@@ -93,17 +98,17 @@ __global__ void __launch_bounds__(256) pfn_kernel(const float* __restrict__ voxe
 {
     pfn_kernel_body(voxels, coors, npts, num_pillars, wT, scale, shift, vx, vy, x_off, y_off, T, feat);
 }
-__global__ void __launch_bounds__(256) pmap_kernel(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gy, int32_t* __restrict__ pmap)
+__global__ void __launch_bounds__(256) pmap_kernel(const int32_t* __restrict__ coors, const int32_t* __restrict__ num_pillars, int gx, int gy, int32_t* __restrict__ pmap)
 {
-    pmap_kernel_body(coors, num_pillars, gy, pmap);
+    pmap_kernel_body(coors, num_pillars, gx, gy, pmap);
 }
 // batched twin: PFN rows and the pillar map of frame blockIdx.z in one launch (the map was filled with -1 by pre_init_b)
 __global__ void __launch_bounds__(256) pfn_pmap_b(const pp_pre_frame* __restrict__ tab, const float* __restrict__ wT, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, float vx, float vy, float x_off, float y_off, int T, int gy, int pmap_blocks)
+                                                  const float* __restrict__ shift, float vx, float vy, float x_off, float y_off, int T, int gx, int gy, int pmap_blocks)
 {
     const pp_pre_frame F = tab[blockIdx.z];
     pfn_kernel_body(F.voxels, F.coors, F.npts, F.num, wT, scale, shift, vx, vy, x_off, y_off, T, F.feat);
-    if ((int)blockIdx.x < pmap_blocks) pmap_kernel_body(F.coors, F.num, gy, F.pmap);
+    if ((int)blockIdx.x < pmap_blocks) pmap_kernel_body(F.coors, F.num, gx, gy, F.pmap);
 }
 
 } // namespace
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(256) pfn_pmap_b(const pp_pre_frame* __restrict
 int pp_pillar_map(pp_ctx* ctx, const int32_t* coors, const int32_t* num_pillars, int32_t* pmap, hipStream_t stream)
 {
     PP_HIP(hipMemsetAsync(pmap, 0xFF, (size_t)ctx->gx * ctx->gy * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(pmap_kernel, dim3(pp_div_up(ctx->cfg.max_voxels, 256)), dim3(256), 0, stream, coors, num_pillars, ctx->gy, pmap);
+    hipLaunchKernelGGL(pmap_kernel, dim3(pp_div_up(ctx->cfg.max_voxels, 256)), dim3(256), 0, stream, coors, num_pillars, ctx->gx, ctx->gy, pmap);
     PP_HIP(hipGetLastError());
     return 0;
 }
@@ -143,7 +148,7 @@ extern "C" int pp_scatter(pp_ctx* ctx, const float* feat, const int32_t* coors, 
     if (!feat || !coors || !num_pillars || !canvas) return pp_fail(ctx, PP_E_ARG, "pp_scatter: null pointer");
     size_t plane = (size_t)ctx->gx * ctx->gy;
     PP_HIP(hipMemsetAsync(canvas, 0, plane * 64 * sizeof(float), stream));
-    hipLaunchKernelGGL(scatter_kernel, dim3(1024), dim3(256), 0, stream, feat, coors, num_pillars, ctx->gy, plane, canvas);
+    hipLaunchKernelGGL(scatter_kernel, dim3(1024), dim3(256), 0, stream, feat, coors, num_pillars, ctx->gx, ctx->gy, plane, canvas);
     PP_HIP(hipGetLastError());
     return 0;
 }
@@ -157,7 +162,7 @@ int pp_pfn_pmap_group(pp_ctx* ctx, int b0, int g, hipStream_t stream)
     const int pmap_blocks = pp_div_up(c.max_voxels, 256);
     const int blocks = pmap_blocks > 256 ? pmap_blocks : 256;
     hipLaunchKernelGGL(pfn_pmap_b, dim3(blocks, 1, g), dim3(256), 0, stream, ctx->d_pre + b0, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift, vx, vy,
-                       x_off, y_off, c.max_num_points, ctx->gy, pmap_blocks);
+                       x_off, y_off, c.max_num_points, ctx->gx, ctx->gy, pmap_blocks);
     PP_HIP(hipGetLastError());
     return 0;
 }

@@ -704,20 +704,24 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
     const int n = c.num_classes;
     for (int i = 0; i < n; ++i)
         if (c.class_end[i] > ctx->A) return pp_fail(ctx, PP_E_ARG, "class range exceeds anchor count");
+    { int rc0_ = pp_stage_mark(ctx, stream, PP_ST_POST); if (rc0_) return rc0_; }
     PP_HIP(hipMemsetAsync(P->hist, 0, (size_t)n * (NBINS + 8) * sizeof(int32_t), stream)); // hist + counters
     hipLaunchKernelGGL(post_filter, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n), dim3(256), 0, stream, cls, mask, c, c.score_threshold,
                        P->thr_bits, P->bin_shift, P->cand_cap, P->cand, P->counters, P->hist);
     hipLaunchKernelGGL(post_thresh, dim3(n), dim3(1024), 0, stream, P->hist, P->counters, P->K);
     hipLaunchKernelGGL(post_gather, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n), dim3(256), 0, stream, P->cand, P->cand_cap, P->counters,
                        P->thr_bits, P->bin_shift, P->shortl);
+    int rc_;
+    if ((rc_ = pp_stage_mark(ctx, stream, PP_ST_POST_TOPK))) return rc_;
     hipLaunchKernelGGL(post_topk, dim3(n), dim3(1024), 0, stream, c, P->cand, P->cand_cap, P->shortl, P->counters, P->K, box, dir,
                        ctx->anchors, nms_mode, P->sel, P->boxes, P->nbox, P->dirl);
+    if ((rc_ = pp_stage_mark(ctx, stream, PP_ST_POST_NMS))) return rc_;
     hipLaunchKernelGGL(nms_mask, dim3(P->cb, P->cb, n), dim3(64), 0, stream, P->nbox, 6, P->counters + 3, 8, P->K, P->cb,
                        c.nms_iou_threshold, nms_mode, P->nmask);
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64 * PP_MAX_CLASSES), 0, stream, c, P->nmask, P->sel, P->boxes, P->dirl, P->counters, P->K, P->cb,
                        P->dirl + (size_t)n * P->K, det, det_count);
     PP_HIP(hipGetLastError());
-    return 0;
+    return pp_stage_mark(ctx, stream, -1);
 }
 
 void pp_post_fill_table(pp_ctx* ctx, int slot, pp_post_frame* f)
@@ -743,7 +747,10 @@ int pp_postprocess_group(pp_ctx* ctx, int b0, int g, float* det, int32_t* det_co
                        P->thr_bits, P->bin_shift, P->cand_cap);
     hipLaunchKernelGGL(post_thresh_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, P->K);
     hipLaunchKernelGGL(post_gather_b, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n, g), dim3(256), 0, stream, tab, P->cand_cap, P->thr_bits, P->bin_shift);
+    int rc_;
+    if ((rc_ = pp_stage_mark(ctx, stream, PP_ST_POST_TOPK))) return rc_;
     hipLaunchKernelGGL(post_topk_b, dim3(n, 1, g), dim3(1024), 0, stream, tab, c, P->cand_cap, P->K, ctx->anchors, nms_mode);
+    if ((rc_ = pp_stage_mark(ctx, stream, PP_ST_POST_NMS))) return rc_;
     hipLaunchKernelGGL(nms_mask_b, dim3(P->cb, P->cb, n * g), dim3(64), 0, stream, tab, n, P->K, P->cb, c.nms_iou_threshold, nms_mode);
     hipLaunchKernelGGL(nms_reduce_b, dim3(1, 1, g), dim3(64 * PP_MAX_CLASSES), 0, stream, tab, c, P->K, P->cb, det + (size_t)b0 * det_fs, det_fs,
                        det_count + (size_t)b0 * PP_DET_COUNT_STRIDE, (int)PP_DET_COUNT_STRIDE);

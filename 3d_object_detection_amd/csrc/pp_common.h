@@ -110,7 +110,8 @@ struct pp_ctx {
     size_t stage_used = 0;
 };
 // stage ids of pp_stage_mark / pp_stage_profile_end
-enum { PP_ST_VOXELIZE = 0, PP_ST_MASK = 1, PP_ST_PFN = 2, PP_ST_CONV = 3, PP_ST_NORM = 4, PP_ST_HEAD = 5, PP_ST_POST = 6, PP_ST_COUNT = 8 };
+enum { PP_ST_VOXELIZE = 0, PP_ST_MASK = 1, PP_ST_PFN = 2, PP_ST_CONV = 3, PP_ST_NORM = 4, PP_ST_HEAD = 5, PP_ST_POST = 6 /* filter + threshold + gather */,
+       PP_ST_POST_TOPK = 7 /* exact top-k + decode */, PP_ST_POST_NMS = 8 /* mask + greedy sweep + flip / range / compaction */, PP_ST_COUNT = 12 };
 int pp_stage_mark(pp_ctx* ctx, hipStream_t stream, int id); // no-op unless stage profiling is on
 
 int pp_fail_hip(pp_ctx* ctx, hipError_t e, const char* what, const char* file, int line);

@@ -118,6 +118,20 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _chk(t, dtype, shape, what):
+    """The stage entry points hand raw pointers to kernels: a CPU tensor, another dtype, a strided view or a short
+    buffer would be a device fault there, where the reference's torch ops raise.  shape: tuple with None = any."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{what}: expected a CUDA tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous tensor")
+    if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+        raise ValueError(f"{what}: expected shape {tuple('*' if s is None else s for s in shape)}, got {tuple(t.shape)}")
+    return t
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -223,13 +237,23 @@ class Engine:
                                             _ptr(voxels), _ptr(coors), _ptr(npts), _ptr(num), _stream()), self.ctx, "pp_voxelize")
         return voxels, coors, npts, num
 
+    def _chk_pillars(self, coors, num, what):
+        _chk(coors, torch.int32, (None, 3), what + ": coors")
+        _chk(num, torch.int32, (1,), what + ": num")
+        if coors.shape[0] > self.max_voxels:
+            raise ValueError(f"{what}: {coors.shape[0]} pillars exceed max_voxels {self.max_voxels}")
+
     def anchor_mask(self, coors, num):
+        self._chk_pillars(coors, num, "anchor_mask")
         mask = self._t((self.A,), torch.uint8)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_anchor_mask(self.ctx, _ptr(coors), _ptr(num), _ptr(mask), _stream()), self.ctx, "pp_anchor_mask")
         return mask
 
     def pfn(self, voxels, coors, npts, num):
+        self._chk_pillars(coors, num, "pfn")
+        _chk(voxels, torch.float32, (coors.shape[0], self.T, self.F), "pfn: voxels")
+        _chk(npts, torch.int32, (coors.shape[0],), "pfn: num_points_per_voxel")
         feat = self._t((max(int(voxels.shape[0]), 1), 64), torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_pfn(self.ctx, _ptr(voxels), _ptr(coors), _ptr(npts), _ptr(num), _ptr(feat), _stream()),
@@ -237,18 +261,24 @@ class Engine:
         return feat
 
     def scatter(self, feat, coors, num):
+        self._chk_pillars(coors, num, "scatter")
+        _chk(feat, torch.float32, (None, 64), "scatter: feat")
+        if feat.shape[0] < coors.shape[0]:
+            raise ValueError("scatter: fewer feature rows than pillars")
         canvas = self._t((1, 64, int(self.grid_size[0]), int(self.grid_size[1])), torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_scatter(self.ctx, _ptr(feat), _ptr(coors), _ptr(num), _ptr(canvas), _stream()), self.ctx, "pp_scatter")
         return canvas
 
     def backbone(self, canvas):
+        _chk(canvas.reshape(-1), torch.float32, (64 * int(self.grid_size[0]) * int(self.grid_size[1]),), "backbone: canvas [1,64,gx,gy]")
         out = self._t((1, 320, self.H, self.W), torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_backbone(self.ctx, _ptr(canvas), _ptr(out), _stream()), self.ctx, "pp_backbone")
         return out
 
     def head(self, rpn_out):
+        _chk(rpn_out.reshape(-1), torch.float32, (320 * self.H * self.W,), "head: rpn_out [1,320,H,W]")
         cls = self._t((1, self.A, 1), torch.float32)
         box = self._t((1, self.A, 7), torch.float32)
         dr = self._t((1, self.A, 2), torch.float32)
@@ -260,6 +290,10 @@ class Engine:
         det = torch.zeros((self.cfg.num_classes * self.cfg.nms_post_max, 9), dtype=torch.float32, device=self.device)
         cnt = torch.zeros((1 + _lib.PP_MAX_CLASSES,), dtype=torch.int32, device=self.device)
         m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        _chk(cls.reshape(-1), torch.float32, (self.A,), "postprocess: cls_preds")
+        _chk(box.reshape(-1), torch.float32, (self.A * 7,), "postprocess: box_preds")
+        _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "postprocess: dir_preds")
+        _chk(m.reshape(-1), torch.uint8, (self.A,), "postprocess: anchors_mask")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_postprocess(self.ctx, _ptr(cls), _ptr(box), _ptr(dr), _ptr(m), _ptr(det), _ptr(cnt),
                                                int(nms_mode), _stream()), self.ctx, "pp_postprocess")
@@ -326,10 +360,12 @@ class Engine:
         _lib.check(self.lib.pp_stage_profile_begin(self.ctx), self.ctx, "pp_stage_profile_begin")
 
     def stage_profile_end(self):
-        ms = (ctypes.c_double * 8)()
+        ms = (ctypes.c_double * 12)()
         _lib.check(self.lib.pp_stage_profile_end(self.ctx, ms), self.ctx, "pp_stage_profile_end")
-        names = ["voxelize", "anchor_mask", "pfn_pmap", "conv", "norm_relu_stats", "head", "postprocess"]
-        return {n: ms[i] for i, n in enumerate(names)}
+        names = ["voxelize", "anchor_mask", "pfn_pmap", "conv", "norm_relu_stats", "head", "post_filter", "post_topk_decode", "post_nms"]
+        out = {n: ms[i] for i, n in enumerate(names)}
+        out["postprocess"] = out["post_filter"] + out["post_topk_decode"] + out["post_nms"]
+        return out
 
     def profile_begin(self):
         _lib.check(self.lib.pp_profile_begin(self.ctx), self.ctx, "pp_profile_begin")
@@ -353,10 +389,11 @@ def engine_for(config, norm=None):
     if eng is None or eng.norm != want:
         dev = config.get("device", torch.device("cuda:0"))
         idx = dev.index if isinstance(dev, torch.device) and dev.index is not None else 0
-        old = eng
-        eng = Engine(config, device_index=idx, norm=want)
-        if old is not None and old.weights_loaded:
-            pass
+        if eng is not None and eng.weights_loaded:
+            # a network of the other norm kind on the same config dict: its state_dict has other tensors (BatchNorm
+            # running stats), so the loaded weights cannot carry over -- say so instead of silently dropping them
+            raise RuntimeError(f"config already drives a '{eng.norm}' network with weights loaded; build the '{want}' network from its own config dict")
+        eng = Engine(config, device_index=idx, norm=want, max_batch=config.get("max_batch"))
         config["_pp_engine"] = eng
         config["_pp_norm"] = want
     return eng

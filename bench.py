@@ -177,7 +177,9 @@ def stage_rooflines(eng, clouds, NB, cfg, passes=3):
         out[k] = {"bound": "mfma", "ms_per_frame": round(per_frame[k], 5), "algorithmic_flops_per_frame": a_, "executed_flops_per_frame": e_,
                   "achieved": round(e_ / t / 1e12, 2) if t > 0 else 0.0, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(e_ / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if t > 0 else 0.0}
-    total = sum(per_frame.values())
+    parts = ("post_filter", "post_topk_decode", "post_nms")
+    out["postprocess"]["parts_ms_per_frame"] = {k: round(per_frame[k], 5) for k in parts}
+    total = sum(v for k, v in per_frame.items() if k not in parts)
     whole = {"gpu_ms_per_frame": round(total, 5), "algorithmic_gflop": round(alg / 1e9, 2), "executed_gflop": round(ex / 1e9, 2),
              "executed_tflops": round(ex / (total * 1e-3) / 1e12, 2) if total > 0 else 0.0,
              "executed_frac": round(ex / (total * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if total > 0 else 0.0,

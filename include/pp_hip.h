@@ -164,9 +164,11 @@ int pp_profile_end(pp_ctx* ctx, double* avg_ms_h, int32_t* launches_h, double* f
 /* executed MFMA flops / algorithmic (direct-convolution) flops of that layer's tiling (Winograd F(2x2,3x3): 4/9) */
 double pp_dominant_executed_ratio(pp_ctx* ctx);
 /* Per-stage GPU time of the fused path: between begin and end every pp_infer_batch pass records one event per stage
- * boundary on its stream; end synchronises and sums the milliseconds per stage into ms_h[8]:
- * 0 voxelise, 1 anchor mask, 2 PFN + pillar map, 3 conv / deconv launches (+ statistics finalisation),
- * 4 norm_relu_stats, 5 head, 6 post-processing (7 unused).  Meant for an untimed side pass of bench.py. */
+ * boundary on its stream (and so does a stand-alone pp_postprocess); end synchronises and sums the milliseconds
+ * per stage into ms_h[12]: 0 voxelise, 1 anchor mask, 2 PFN + pillar map, 3 conv / deconv launches (+ statistics
+ * finalisation), 4 norm_relu_stats, 5 head, 6 post-processing filter (mask, sigmoid, threshold, candidate gather),
+ * 7 exact top-k + box decode, 8 NMS + direction flip / range mask / compaction (9-11 unused).
+ * Meant for an untimed side pass of bench.py and for the drop-in classes' p1..p4 / stage timers. */
 int pp_stage_profile_begin(pp_ctx* ctx);
 int pp_stage_profile_end(pp_ctx* ctx, double* ms_h);
 /* The network's launch plan as text, one line per conv / deconv / head layer in execution order:

@@ -100,6 +100,22 @@ def test_frame_dropin_vs_reference(tag, fw, synth, eight_ref):
     cnt = np.array([det.shape[0]] + [int((ci == k).sum()) for k in range(len(names))])
     gl = dict(cls=cls.reshape(-1), box=box.reshape(-1, 7), dir=dr.reshape(-1, 2), mask=example["anchors_mask"].cpu().numpy().reshape(-1))
     compare_frame(r, gl, det.astype(np.float32), cnt, "aabb", f"drop-in eight_20cm {tag}")
+    # the reference's second post-processing path (inference.py:140-256), stage by stage: same detections as the fused call
+    # (tie-free scores; the direction flip adds pi in fp32 there, in fp64 in infer_gpu -> 1e-6 on the angle)
+    a2 = inference.infer_torch(example, preds)[0]
+    assert list(a2["name"]) == list(annos["name"])
+    for key in ("location", "dimensions", "rotation_y", "score"):
+        np.testing.assert_allclose(a2[key], annos[key], rtol=1e-6, atol=2e-5)
+    # module functions nms / nms_torch (inference.py:689-721)
+    d = golden("nms_aabb")["dets_300"]
+    keep = fw["inf"].nms(d[:, :4], d[:, 4], post_max_size=50, iou_threshold=0.1)
+    keep_t = fw["inf"].nms_torch(torch.from_numpy(d[:, :4]).cuda(), torch.from_numpy(d[:, 4]).cuda(), post_max_size=50, iou_threshold=0.1)
+    assert list(keep) == [int(v) for v in golden("nms_aabb")["keep_300"][:50]] == keep_t.tolist()
+    assert fw["inf"].nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32)) is None
+    # the reference's timing buckets are really advanced (train.py:244-258 prints them per frame)
+    assert inference.p1 > 0 and inference.p2 > 0 and inference.p3 > 0 and inference.p4 > 0
+    assert infer_data.voxel_time > 0 and infer_data.mask_time > 0 and infer_data.convert_time > 0
+    assert net.pfn_time > 0 and net.rpn_time > 0 and net.heads_time > 0 and net.scatter_time > 0
 
 
 @pytest.mark.parametrize("tag", ["rand", "trained"])

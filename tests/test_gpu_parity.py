@@ -169,6 +169,38 @@ def test_pfn_T100_and_scatter(fw, synth):
     assert np.array_equal(canvas, O.scatter(feat.cpu().numpy(), c, s["grid_size"]))
 
 
+def test_bad_stage_inputs_do_not_reach_the_device(fw, synth):
+    """Out-of-grid coordinates and an over-long point count are skipped / clamped by the kernels; wrong tensors raise."""
+    cfg = make_cfg(synth, "nuscene")
+    vgen = fw["vg"].VoxelGenerator(cfg)
+    net = fw["shared"].PointPillars(cfg)
+    d = torch.device("cuda:0")
+    v, c, n = vgen.generate(synth.lidar_cloud("nuscene", seed=3, n_points=4000))
+    vt, ct, nt = torch.from_numpy(v).to(d), torch.from_numpy(c).to(d), torch.from_numpy(n).to(d)
+    feat = net.pillar_point_net(vt, nt, ct)
+    good = net.middle_feature_extractor(feat, ct)
+    bad_c = ct.clone()
+    bad_c[0, 0] = 100000   # far outside the 512 x 480 grid
+    bad_c[1, 1] = -7
+    canvas = net.middle_feature_extractor(feat, bad_c)
+    torch.cuda.synchronize()
+    ref = good.clone()
+    for k in (0, 1):       # the two bad pillars are simply absent
+        ref[0, :, int(c[k, 0]), int(c[k, 1])] = 0
+    assert torch.equal(canvas, ref)
+    nt2 = nt.clone()
+    nt2[0] = 10 ** 6       # a count beyond T reads at most the pillar's own T slots
+    f2 = net.pillar_point_net(vt, nt2, ct)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f2).all() and torch.equal(f2[1:], feat[1:])
+    with pytest.raises(TypeError):
+        net.middle_feature_extractor(feat, ct.long())
+    with pytest.raises(TypeError):
+        net.middle_feature_extractor(feat.cpu(), ct)
+    with pytest.raises(ValueError):
+        net.pillar_point_net(vt[:, :7], nt, ct)
+
+
 # ------------------------------------------------------------------ a8/a9 backbone + head (small grids, golden)
 def small_cfg(synth, gx, gy):
     cfg = synth.load_config("eight_20cm")

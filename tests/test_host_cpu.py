@@ -158,3 +158,31 @@ def test_class_table_from_config(synth):
     assert eng.class_table_of(synth.load_config("nuscene"))[0] == ["vehicle", "pedestrian", "cyclist"]
     sd = synth.seeded_state_dict(0, num_anchor_per_loc=20)
     assert sd["heads.conv_cls.weight"].shape[0] == 20 and sd["heads.conv_box.weight"].shape[0] == 140 and sd["heads.conv_dir.bias"].shape[0] == 40
+
+
+def test_stage_inputs_are_validated():
+    """the stage entry points hand raw pointers to kernels, so a CPU tensor / wrong dtype / strided view /
+    wrong shape must raise on the host (the reference's torch ops raise there), never reach the device."""
+    import torch
+    eng = load_pkg("engine")
+    with pytest.raises(TypeError):
+        eng._chk(torch.zeros(4, 3, dtype=torch.int32), torch.int32, (None, 3), "coors")          # CPU tensor
+    with pytest.raises(TypeError):
+        eng._chk(np.zeros((4, 3), np.int32), torch.int32, (None, 3), "coors")                     # not a tensor
+
+    class FakeCuda(torch.Tensor):  # a CPU tensor that claims to be on the device: exercises the remaining checks here
+        @property
+        def is_cuda(self):
+            return True
+
+    t = torch.zeros(4, 3, dtype=torch.int64).as_subclass(FakeCuda)
+    with pytest.raises(TypeError):
+        eng._chk(t, torch.int32, (None, 3), "coors")                                              # int64 coordinates
+    t = torch.zeros(3, 8, dtype=torch.int32).t().as_subclass(FakeCuda)
+    with pytest.raises(ValueError):
+        eng._chk(t, torch.int32, (None, 3), "coors")                                              # strided view
+    t = torch.zeros(4, 4, dtype=torch.int32).as_subclass(FakeCuda)
+    with pytest.raises(ValueError):
+        eng._chk(t, torch.int32, (None, 3), "coors")                                              # wrong shape
+    ok = torch.zeros(4, 3, dtype=torch.int32).as_subclass(FakeCuda)
+    assert eng._chk(ok, torch.int32, (None, 3), "coors") is ok
