@@ -65,6 +65,8 @@ PROTOTYPES = {
                                           ctypes.c_int, c_p, c_p, c_p]),
     "pp_eval_fused_statistics": (ctypes.c_int, [c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int, c_p, c_p, c_p, ctypes.c_double, c_p,
                                                 ctypes.c_int]),
+    "pp_eval_class_ap": (ctypes.c_int, [ctypes.POINTER(c_p), c_p, ctypes.c_int, c_p, c_p, c_i64, c_p, c_p, c_p, ctypes.c_double, c_i64, ctypes.c_int,
+                                        c_p, c_p]),
     "pp_profile_begin": (ctypes.c_int, [c_p]),
     "pp_profile_end": (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
     "pp_dominant_kernel": (ctypes.c_char_p, [c_p]),

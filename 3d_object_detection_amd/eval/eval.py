@@ -5,9 +5,12 @@ What runs where:
 * rotated BEV overlaps: on the device, ONE `pp_rotated_iou_eval` launch for all frames of a part (eval/iou.py:606-638);
 * the height term of the 3-D overlap (d3_box_overlap_kernel_lidar, eval.py:148-170): vectorised numpy in the dtype
   the annos carry, as the reference's numba loop computes it;
-* the greedy matching (compute_statistics_jit / fused_compute_statistics, eval.py:62-119,182-216): native host code
-  in libpp_hip.so (`pp_eval_statistics`, `pp_eval_fused_statistics`) instead of numba;
-* the bookkeeping around it: Python, as in the reference.
+* the AP table: the data set is flattened once (`_Scene`: CSR over frames), the ignore codes of a class are one vectorised
+  pass over all boxes, and each (class, overlap threshold) cell is ONE native call (`pp_eval_class_ap`: matching at
+  threshold 0, the 41 recall-sampled score thresholds, tp/fp/fn per threshold, precision / recall with the running
+  maximum) -- no Python loop over frames;
+* compute_statistics_jit / fused_compute_statistics (eval.py:62-119,182-216) remain available with the reference's
+  signatures on the same native matcher (`pp_eval_statistics`, `pp_eval_fused_statistics`).
 The camera-frame variants (calculate_iou_partly_camera, d3_box_overlap_camera) are not on this repository's path
 (`frame = 'lidar'` is hard-coded at eval.py:467) and are not provided.
 """
@@ -25,24 +28,29 @@ def get_range(x, y):
     return np.sqrt(x * x + y * y)
 
 
-def clean_data(gt_anno, dt_anno, current_class, num_points_thresh, range_thresh):
-    """eval.py:10-39, vectorised: ignored codes -1 (other class / no points / out of range), 0 (counts), 1 (too few
-    points: matched detections are not false positives)."""
-    cls = current_class.lower()
-    gname = np.char.lower(np.asarray(gt_anno["name"], dtype=str)) if len(gt_anno["name"]) else np.zeros((0,), dtype=str)
-    dname = np.char.lower(np.asarray(dt_anno["name"], dtype=str)) if len(dt_anno["name"]) else np.zeros((0,), dtype=str)
+def _ignore_codes(gname, gloc, gnpts, dname, dloc, cls, num_points_thresh, range_thresh):
+    """The reference's per-box ignore codes (eval.py:10-39) for any number of boxes at once: -1 other class / no points /
+    out of range, 0 counts, 1 too few points (a detection matched to it is not a false positive)."""
     ignored_gt = np.full(gname.shape[0], -1, dtype=np.int64)
     if gname.shape[0]:
-        loc = np.asarray(gt_anno["location"])
-        npts = np.asarray(gt_anno["num_points"])
-        live = (gname == cls) & (npts != 0) & (get_range(loc[:, 0], loc[:, 1]) < range_thresh)
-        ignored_gt[live & (npts > num_points_thresh)] = 0
-        ignored_gt[live & ~(npts > num_points_thresh)] = 1
+        live = (gname == cls) & (gnpts != 0) & (get_range(gloc[:, 0], gloc[:, 1]) < range_thresh)
+        ignored_gt[live] = np.where(gnpts[live] > num_points_thresh, 0, 1)
     ignored_dt = np.full(dname.shape[0], -1, dtype=np.int64)
     if dname.shape[0]:
-        loc = np.asarray(dt_anno["location"])
-        ignored_dt[(dname == cls) & (get_range(loc[:, 0], loc[:, 1]) < range_thresh)] = 0
-    return int((ignored_gt == 0).sum()), ignored_gt.tolist(), ignored_dt.tolist()
+        ignored_dt[(dname == cls) & (get_range(dloc[:, 0], dloc[:, 1]) < range_thresh)] = 0
+    return ignored_gt, ignored_dt
+
+
+def _lower_names(anno):
+    return np.char.lower(np.asarray(anno["name"], dtype=str)) if len(anno["name"]) else np.zeros((0,), dtype=str)
+
+
+def clean_data(gt_anno, dt_anno, current_class, num_points_thresh, range_thresh):
+    """eval.py:10-39 for one frame -> (num_valid_gt, ignored_gt list, ignored_dt list)."""
+    ig, idt = _ignore_codes(_lower_names(gt_anno), np.asarray(gt_anno["location"]).reshape(-1, 3), np.asarray(gt_anno["num_points"]).reshape(-1),
+                            _lower_names(dt_anno), np.asarray(dt_anno["location"]).reshape(-1, 3), current_class.lower(), num_points_thresh,
+                            range_thresh)
+    return int((ig == 0).sum()), ig.tolist(), idt.tolist()
 
 
 def get_thresholds(scores, num_gt, num_sample_pts=41):
@@ -183,60 +191,58 @@ def calculate_iou_partly_lidar(gt_annos, dt_annos, metric='bev', num_parts=50):
     return overlaps, parted_overlaps, total_gt_num, total_dt_num
 
 
-def _prepare_data(gt_annos, dt_annos, current_class, num_points_thresh, range_thresh):
-    """eval.py:349-360."""
-    ignored_gts, ignored_dets, dt_score_list = [], [], []
-    total_num_valid_gt = 0
-    for gt, dt in zip(gt_annos, dt_annos):
-        num_valid_gt, ignored_gt, ignored_det = clean_data(gt, dt, current_class, num_points_thresh, range_thresh=range_thresh)
-        ignored_gts.append(np.array(ignored_gt, dtype=np.int64))
-        ignored_dets.append(np.array(ignored_det, dtype=np.int64))
-        dt_score_list.append(np.asarray(dt["score"]).astype('float32'))
-        total_num_valid_gt += num_valid_gt
-    return ignored_gts, ignored_dets, dt_score_list, total_num_valid_gt
+class _Scene:
+    """All frames of an evaluation as flat arrays (CSR over frames): the ignore codes of a class are then ONE vectorised
+    pass over every box of the data set and the AP of a (class, overlap threshold) cell ONE native call
+    (pp_eval_class_ap), instead of Python loops over frames around per-frame native calls."""
+
+    def __init__(self, gt_annos, dt_annos):
+        assert len(gt_annos) == len(dt_annos)
+        self.n = len(gt_annos)
+        self.gt_nums = np.array([len(a["name"]) for a in gt_annos], dtype=np.int64)
+        self.dt_nums = np.array([len(a["name"]) for a in dt_annos], dtype=np.int64)
+        cat = lambda annos, key, tail, dt: (np.concatenate([np.asarray(a[key], dtype=dt).reshape((-1,) + tail) for a in annos], 0)
+                                            if annos else np.zeros((0,) + tail, dt))
+        self.gt_name = np.concatenate([_lower_names(a) for a in gt_annos]) if self.n else np.zeros((0,), str)
+        self.dt_name = np.concatenate([_lower_names(a) for a in dt_annos]) if self.n else np.zeros((0,), str)
+        self.gt_loc = cat(gt_annos, "location", (3,), np.float64)
+        self.dt_loc = cat(dt_annos, "location", (3,), np.float64)
+        self.gt_npts = cat(gt_annos, "num_points", (), np.int64)
+        self.dt_score = cat(dt_annos, "score", (), np.float32)
+        self._gt_annos, self._dt_annos = gt_annos, dt_annos
+
+    def overlaps(self, metric, num_parts):
+        """Part-wise overlap matrices [detections of the part][ground truths of the part] (float64, C order) -- one device
+        launch per part, as calculate_iou_partly_lidar(dt_annos, gt_annos, ...) of eval.py:377-383 -- and the frames per part."""
+        _, parted, _, _ = calculate_iou_partly_lidar(self._dt_annos, self._gt_annos, metric, num_parts)
+        frames = np.array([p for p in get_split_parts(self.n, num_parts)], dtype=np.int64)
+        return [np.ascontiguousarray(m, dtype=np.float64) for m in parted], frames
+
+    def class_ap(self, parts, part_frames, cls, min_overlap, num_points_thresh, range_thresh, n_sample_pts=41, codes=None):
+        ig, idt = codes if codes is not None else _ignore_codes(self.gt_name, self.gt_loc, self.gt_npts, self.dt_name, self.dt_loc, cls.lower(),
+                                                                num_points_thresh, range_thresh)
+        prec = np.zeros(n_sample_pts, dtype=np.float64)
+        rec = np.zeros(n_sample_pts, dtype=np.float64)
+        ptrs = (ctypes.c_void_p * max(len(parts), 1))(*[m.ctypes.data if m.size else None for m in parts])
+        _lib.check(_lib.load().pp_eval_class_ap(ptrs, _p(part_frames), len(parts), _p(self.dt_nums), _p(self.gt_nums), self.n, _p(ig), _p(idt),
+                                                _p(self.dt_score), float(min_overlap), int((ig == 0).sum()), n_sample_pts, _p(prec), _p(rec)),
+                   None, "pp_eval_class_ap")
+        return prec, rec
 
 
 def eval_class_AP(gt_annos, dt_annos, class_names, metric, min_overlaps, frame, num_points_thresh, range_thresh, num_parts=50):
-    """eval.py:363-440."""
-    assert len(gt_annos) == len(dt_annos)
+    """Signature and return value of eval.py:363-440: {"recall", "precision"} as [class, overlap threshold, 41 recall samples]."""
     if frame != 'lidar':
         raise ValueError("only the lidar frame is on this repository's path (eval.py:467)")
-    num_examples = len(gt_annos)
-    split_parts = get_split_parts(num_examples, num_parts)
-    # the reference calls this with (dt_annos, gt_annos): rows = detections, columns = ground truth (:377-383)
-    overlaps, parted_overlaps, total_dt_num, total_gt_num = calculate_iou_partly_lidar(dt_annos, gt_annos, metric, num_parts)
-    N_SAMPLE_PTS = 41
-    num_minoverlap = len(list(min_overlaps.values())[0])
-    num_class = len(class_names)
-    precision = np.zeros([num_class, num_minoverlap, N_SAMPLE_PTS])
-    recall = np.zeros([num_class, num_minoverlap, N_SAMPLE_PTS])
-    empty_i = np.zeros((0,), dtype=np.int64)
-    for m, current_class in enumerate(class_names):
-        ignored_gts, ignored_dets, dt_score_list, total_num_valid_gt = _prepare_data(gt_annos, dt_annos, current_class, num_points_thresh,
-                                                                                     range_thresh=range_thresh)
-        for k, min_overlap in enumerate(min_overlaps[current_class]):
-            thresholdss = []
-            for i in range(num_examples):
-                _, _, _, thresholds = compute_statistics_jit(overlaps[i], ignored_gts[i], ignored_dets[i], dt_score_list[i],
-                                                             min_overlap=min_overlap, thresh=0.0, compute_fp=False)
-                thresholdss += thresholds.tolist()
-            thresholds = np.array(get_thresholds(np.array(thresholdss), total_num_valid_gt))
-            pr = np.zeros([len(thresholds), 4])
-            idx = 0
-            for j, num_part in enumerate(split_parts):
-                if num_part:
-                    fused_compute_statistics(parted_overlaps[j], pr, total_gt_num[idx:idx + num_part], total_dt_num[idx:idx + num_part],
-                                             np.concatenate(ignored_gts[idx:idx + num_part] + [empty_i], 0),
-                                             np.concatenate(ignored_dets[idx:idx + num_part] + [empty_i], 0),
-                                             np.concatenate(dt_score_list[idx:idx + num_part] + [np.zeros((0,), np.float32)], 0),
-                                             min_overlap=min_overlap, thresholds=thresholds)
-                idx += num_part
-            with np.errstate(all="ignore"):
-                for i in range(len(thresholds)):
-                    recall[m, k, i] = pr[i, 0] / (pr[i, 0] + pr[i, 2])
-                    precision[m, k, i] = pr[i, 0] / (pr[i, 0] + pr[i, 1])
-            for i in range(len(thresholds)):
-                precision[m, k, i] = np.max(precision[m, k, i:], axis=-1)
+    scene = _Scene(gt_annos, dt_annos)
+    parts, part_frames = scene.overlaps(metric, num_parts)
+    n_thr = len(next(iter(min_overlaps.values())))
+    precision = np.zeros([len(class_names), n_thr, 41])
+    recall = np.zeros([len(class_names), n_thr, 41])
+    for m, cls in enumerate(class_names):
+        codes = _ignore_codes(scene.gt_name, scene.gt_loc, scene.gt_npts, scene.dt_name, scene.dt_loc, cls.lower(), num_points_thresh, range_thresh)
+        for k, min_overlap in enumerate(min_overlaps[cls]):
+            precision[m, k], recall[m, k] = scene.class_ap(parts, part_frames, cls, min_overlap, num_points_thresh, range_thresh, codes=codes)
     return {"recall": recall, "precision": precision}
 
 

@@ -155,6 +155,16 @@ int pp_eval_fused_statistics(const double* overlaps, int64_t ov_ld, double* pr, 
                              int n_frames, const int64_t* ignored_gts, const int64_t* ignored_dets, const float* dt_scores,
                              double min_overlap, const double* thresholds, int n_thresholds);
 
+/* One (class, overlap threshold) cell of the AP table in one call: the loop nest of eval/eval.py:396-434 (per-frame
+ * compute_statistics_jit at threshold 0, get_thresholds :42-59, fused_compute_statistics per part, precision / recall and
+ * the running maximum).  parts_h[j]: row-major [detections of part j][ground truths of part j] overlaps; part_frames_h:
+ * frames per part; *_nums_h per frame; ignored_* (-1/0/1 codes) and dt_scores concatenated in frame order.
+ * precision_h / recall_h: n_sample_pts (41) doubles, zero behind the last threshold like the reference's np.zeros. */
+int pp_eval_class_ap(const double* const* parts_h, const int64_t* part_frames_h, int n_parts, const int64_t* dt_nums_h,
+                     const int64_t* gt_nums_h, int64_t n_frames, const int64_t* ignored_gt_h, const int64_t* ignored_dt_h,
+                     const float* dt_scores_h, double min_overlap, int64_t num_valid_gt, int n_sample_pts, double* precision_h,
+                     double* recall_h);
+
 /* Measurement hooks for bench.py: between begin and end every launch of the dominant kernel
  * (conv3x3 stride 1 on the level-0 map, 3 launches per frame) is bracketed by hipEvents on the
  * launch stream.  pp_profile_end synchronises the events and reports the average duration (ms),

@@ -69,6 +69,36 @@ def test_clean_data_thresholds_and_map_equal_oracle():
     assert ev.get_split_parts(53, 50) == [1] * 50 + [3] and ev.get_split_parts(100, 50) == [2] * 50
 
 
+def test_native_class_ap_equals_oracle():
+    """pp_eval_class_ap (one call per (class, overlap threshold) cell over the flattened data set) against the oracle's
+    restatement of the reference's loop nest, on oracle-computed overlaps (no device needed): parts of 1, of 7 and one
+    part for everything, ragged / empty frames included."""
+    ev = load_pkg("eval.eval")
+    _, gts, dts = load_sets()
+    gts, dts = gts[:23], dts[:23]
+    want = E.eval_class_ap(gts, dts, CLASSES, "bev", ev.MIN_OVERLAPS, 5, 60.0)
+    ovs = [np.ascontiguousarray(E.frame_overlaps(dts[i], gts[i], "bev")) for i in range(len(gts))]
+    scene = ev._Scene(gts, dts)
+    for per in (1, 7, 23):
+        parts, frames = [], []
+        for f0 in range(0, len(gts), per):
+            fs = range(f0, min(f0 + per, len(gts)))
+            nd, ng = sum(ovs[f].shape[0] for f in fs), sum(ovs[f].shape[1] for f in fs)
+            m = np.full((nd, ng), 0.123)  # off-diagonal blocks hold overlaps of boxes of DIFFERENT frames: must never be read
+            d0 = g0 = 0
+            for f in fs:
+                m[d0:d0 + ovs[f].shape[0], g0:g0 + ovs[f].shape[1]] = ovs[f]
+                d0 += ovs[f].shape[0]
+                g0 += ovs[f].shape[1]
+            parts.append(np.ascontiguousarray(m))
+            frames.append(len(fs))
+        for mi, cls in enumerate(CLASSES):
+            for k, mo in enumerate(ev.MIN_OVERLAPS[cls]):
+                prec, rec = scene.class_ap(parts, np.array(frames, np.int64), cls, mo, 5, 60.0)
+                np.testing.assert_allclose(prec, want["precision"][mi, k], rtol=0, atol=1e-12, equal_nan=True)
+                np.testing.assert_allclose(rec, want["recall"][mi, k], rtol=0, atol=1e-12, equal_nan=True)
+
+
 @pytest.mark.gpu
 def test_rotate_iou_gpu_eval_criteria():
     iou = load_pkg("eval.iou")
