@@ -1923,7 +1923,21 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
 //   registers, and feeds the MFMAs -- every wave streams on its own, no workgroup barrier
 // * pixels are flattened (a 1x1 conv has no neighbourhood), N-tile = 16 consecutive pixels
 // ------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
+// PREC (the reference's deployed path is TensorRT FP16, framework/trt_utils.py:30): 0 = fp32 MFMA (exact);
+// 1 = split-bf16 "bf16x3": x = hi + lo with hi = bf16(x), lo = bf16(x - hi), a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+// v_mfma_f32_16x16x16_bf16 with fp32 accumulation (~2^-16 relative per product: fp32-equivalent for this network, three MFMAs at
+// 8x the fp32-MFMA rate); 2 = plain bf16 operands (one MFMA, ~2^-8 per product: the reduced-precision deploy mode).
+// Activations stay fp32 in HBM: normalise + ReLU in fp32, then split / round while staging.  The weight slab in LDS is
+// [K/16][hi|lo][k-group 0..3][BMP rows][4 bf16] -- the same bytes as the fp32 slab.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) // v_cvt_pk_bf16_f32 (round to nearest even)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+
+template <int MT, int NT, int EPI, int PREC = 0>
 __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 {
     constexpr int BM = MT * 16;
@@ -2032,10 +2046,12 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PAR][i], b[PAR][j], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
+    if constexpr (PREC == 0) {
     if (gw < total) {
         set_load_item(gw);
 #pragma unroll
         for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
+    }
     }
     for (int item = gw; item < total; item += gstride) {
         const int fr = __builtin_amdgcn_readfirstlane(item / items_per_frame);
@@ -2070,6 +2086,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (PREC == 0) {
         // K % (4 * PD) == 0 (layer_menu offers this kernel only then): no tail steps.
         // Per step: the B quad of step st+PD-1 is requested (buffer load: lane offset in a VGPR, the channel-quad
         // offset in an SGPR -- no address VALU), the A fragments and the normalised B values of step st+1 are
@@ -2100,6 +2117,59 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             set_load_item(item + gstride);
 #pragma unroll
             for (int s0 = 0; s0 < PD - 1; ++s0) G1_LOADB(s0, s0)
+        }
+
+        } else {
+            // ---- reduced-precision K loop: 16 input channels per block = one bf16 MFMA depth.  Lane (pixel group m, k-group kq)
+            //      loads channels kq*4 .. kq*4+3 of the block for its 4 pixels (4 dwordx4, block kb+1 in flight behind block kb),
+            //      normalises in fp32, packs 4 channels of one pixel into one B operand (two v_cvt_pk_bf16_f32) ----
+            set_load_item(item);
+            const unsigned bvq = bvoff + (unsigned)kq * 3u * (unsigned)plane * 4u; // (kq*4*plane + pixel)*4: bvoff already holds kq*plane
+            const unsigned cstep = (unsigned)plane * 4u;                            // bytes between channels
+            const uint2* wl2 = reinterpret_cast<const uint2*>(wl);
+            const int nkb = K / 16;
+            f32x4 q0[4], q1[4];
+#define G1_LP_LOAD(Q, KB) _Pragma("unroll") for (int t = 0; t < 4; ++t) Q[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0));
+#define G1_LP_BLOCK(Q, KB)                                                                       \
+    {                                                                                            \
+        f32x4 sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = (f32x4){0.f, 0.f, 0.f, 0.f};              \
+        if (p.pre != PRE_RAW) { sc4 = *reinterpret_cast<const f32x4*>(scl + (KB) * 16 + kq * 4); sh4 = *reinterpret_cast<const f32x4*>(shl + (KB) * 16 + kq * 4); } \
+        s16x4 bh[NT], bl[NT];                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
+            float v_[4];                                                                         \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) v_[t] = (p.pre != PRE_RAW) ? fmaxf(fmaf(Q[t][j], sc4[t], sh4[t]), 0.f) : Q[t][j]; \
+            const unsigned h0 = pk_bf16(v_[0], v_[1]), h1 = pk_bf16(v_[2], v_[3]);               \
+            bh[j] = __builtin_bit_cast(s16x4, (uint2){h0, h1});                                  \
+            if constexpr (PREC == 1) {                                                           \
+                const float l0 = v_[0] - __uint_as_float(h0 << 16), l1 = v_[1] - __uint_as_float(h0 & 0xFFFF0000u); \
+                const float l2 = v_[2] - __uint_as_float(h1 << 16), l3 = v_[3] - __uint_as_float(h1 & 0xFFFF0000u); \
+                bl[j] = __builtin_bit_cast(s16x4, (uint2){pk_bf16(l0, l1), pk_bf16(l2, l3)});    \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
+            const s16x4 ah = __builtin_bit_cast(s16x4, wl2[(((KB) * 2 + 0) * 4 + kq) * BMP + i * 16 + m]); \
+            s16x4 al = ah;                                                                       \
+            if constexpr (PREC == 1) al = __builtin_bit_cast(s16x4, wl2[(((KB) * 2 + 1) * 4 + kq) * BMP + i * 16 + m]); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[j], acc[i][j], 0, 0, 0); \
+                if constexpr (PREC == 1) {                                                       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[j], acc[i][j], 0, 0, 0); \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+    }
+            __builtin_amdgcn_s_setprio(0);
+            G1_LP_LOAD(q0, 0)
+            for (int kb = 0; kb < nkb; kb += 2) { // K % 32 == 0: whole pairs of blocks
+                G1_LP_LOAD(q1, kb + 1)
+                G1_LP_BLOCK(q0, kb)
+                if (kb + 2 < nkb) G1_LP_LOAD(q0, kb + 2)
+                G1_LP_BLOCK(q1, kb + 1)
+            }
+            __builtin_amdgcn_s_setprio(1);
+#undef G1_LP_LOAD
+#undef G1_LP_BLOCK
         }
 
         // ---- epilogue of this item (lane m owns pixels pxb .. pxb+3, one per N-tile) ----
@@ -2281,6 +2351,7 @@ struct Variant { // one compiled tiling of conv_mfma
     char name[48];
     int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
     int cin = 0;  // wino == 2: compiled for exactly this Cin
+    int prec = 0; // wino == 3: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -2339,16 +2410,18 @@ Variant make_wres()
     return v;
 }
 
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, int PREC = 0>
 Variant make_g1()
 {
     Variant v;
-    v.kern = gemm1x1<MT, NT, EPI>;
+    v.kern = gemm1x1<MT, NT, EPI, PREC>;
+    v.prec = PREC;
     v.bm = MT * 16; v.bmp = v.bm + ((v.bm % 32 == 0) ? 16 : 0); v.pw = NT * 16; v.ph = 1; v.kc = 4; v.threads = 512;
     v.waves = 8; v.pairs = MT * NT;
     v.lds = 0; // depends on K: set per layer
     v.wino = 3;
-    snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d", MT, NT, EPI);
+    if (PREC) snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d p%d", MT, NT, EPI, PREC);
+    else snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d", MT, NT, EPI);
     return v;
 }
 
@@ -2417,9 +2490,24 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true)
+template <int PREC>
+void lp_menu(int kind, int up, std::vector<Variant>& menu)
+{
+    if (kind == 2) { menu.push_back(make_g1<6, 4, EPI_HEAD, PREC>()); menu.push_back(make_g1<3, 4, EPI_HEAD, PREC>()); }
+    else if (up == 1) { menu.push_back(make_g1<4, 4, EPI_PLAIN, PREC>()); menu.push_back(make_g1<2, 4, EPI_PLAIN, PREC>()); }
+    else if (up == 2) { menu.push_back(make_g1<4, 4, EPI_UP2, PREC>()); menu.push_back(make_g1<8, 4, EPI_UP2, PREC>()); }
+    else { menu.push_back(make_g1<4, 4, EPI_UP4, PREC>()); menu.push_back(make_g1<8, 4, EPI_UP4, PREC>()); }
+}
+
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true, int prec = 0)
 {
     const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
+    // reduced-precision mode (pp_set_precision): the 1x1 contractions -- the three ConvTranspose(k = s) upsamplers and the
+    // 9-anchor head -- run ONLY their bf16x3 / bf16 tilings; the 3x3 convolutions stay on the fp32 MFMA kernels
+    if (prec && g1ok && (kind == 1 || (kind == 2 && head9))) {
+        if (prec == 1) lp_menu<1>(kind, up, menu); else lp_menu<2>(kind, up, menu);
+        return;
+    }
     if (kind == 2) {
         // the persistent 1x1 GEMM's head epilogue (head_tile_row) is laid out for the reference's 9 anchors per location
         if (g1ok && head9) { menu.push_back(make_g1<6, 4, EPI_HEAD>()); menu.push_back(make_g1<3, 4, EPI_HEAD>()); }
@@ -2477,7 +2565,7 @@ size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 *
 Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout, bool head9 = true)
 {
     std::vector<Variant> menu;
-    layer_menu(kind, stride, up, menu, 0, false, head9);
+    layer_menu(kind, stride, up, menu, 0, false, head9, 0);
     double best = 1e30;
     Variant bv = menu[0];
     for (const Variant& v : menu) {
@@ -2584,6 +2672,29 @@ int pack_layer(pp_ctx* ctx, Layer& L)
             if (src >= 0) memcpy(&perm[(size_t)t * L.cin], &rowsW[(size_t)src * L.cin], sizeof(float) * L.cin);
         }
         rowsW.swap(perm);
+    }
+    if (v.wino == 3 && v.prec) { // [row block][K/16][hi|lo][k-group][BMP][4 bf16]: the byte count of the fp32 slab
+        auto bf16 = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+        auto bf16f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        const int nb_ = pp_div_up(rows, v.bm), nkb = L.cin / 16;
+        std::vector<uint16_t> pk4((size_t)nb_ * nkb * 2 * 4 * v.bmp * 4, 0);
+        for (int b = 0; b < nb_; ++b)
+            for (int kb = 0; kb < nkb; ++kb)
+                for (int q = 0; q < 4; ++q)
+                    for (int mm = 0; mm < v.bm; ++mm) {
+                        const int row = b * v.bm + mm;
+                        if (row >= rows) continue;
+                        for (int t = 0; t < 4; ++t) {
+                            const float w = rowsW[(size_t)row * L.cin + kb * 16 + q * 4 + t];
+                            const uint16_t hi = bf16(w), lo = bf16(w - bf16f(hi));
+                            pk4[(((((size_t)b * nkb + kb) * 2 + 0) * 4 + q) * v.bmp + mm) * 4 + t] = hi;
+                            pk4[(((((size_t)b * nkb + kb) * 2 + 1) * 4 + q) * v.bmp + mm) * 4 + t] = lo;
+                        }
+                    }
+        if (L.w) (void)hipFree(L.w);
+        PP_HIP(hipMalloc((void**)&L.w, pk4.size() * sizeof(uint16_t)));
+        PP_HIP(hipMemcpy(L.w, pk4.data(), pk4.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        return 0;
     }
     if (v.wino == 3) { // [row block][K][BMP]
         const int nb_ = pp_div_up(rows, v.bm);
@@ -2815,11 +2926,11 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
     std::vector<Variant> menu;
-    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9);
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, ctx->precision);
     // the key carries the library version and the menu size (an entry of another build's menu is not trusted), not the
     // device index: the GPUs of a node are identical, and ranks must be able to share rank 0's table
-    snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
-             ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES);
+    snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d p%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
+             ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES, ctx->precision);
     const int rows = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)

@@ -139,7 +139,9 @@ def _stream():
 class Engine:
     """Owns a pp_ctx.  Created lazily through engine_for(config)."""
 
-    def __init__(self, config, device_index=0, norm="instance", max_points=None, max_batch=None):
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+    def __init__(self, config, device_index=0, norm="instance", max_points=None, max_batch=None, precision="fp32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("3d_object_detection_amd needs a ROCm GPU: the HIP path has no CPU fallback")
@@ -192,6 +194,10 @@ class Engine:
             _lib.check(self.lib.pp_set_anchors(self.ctx, self.anchors_np.ctypes.data_as(ctypes.c_void_p),
                                                self.rects_np.ctypes.data_as(ctypes.c_void_p), self.A), self.ctx, "pp_set_anchors")
         self.weights_loaded = False
+        self._sd = None
+        self.precision = "fp32"
+        if precision != "fp32":
+            self.set_precision(precision)
         self._P1 = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def __del__(self):
@@ -203,6 +209,18 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ weights
+    def set_precision(self, mode):
+        """Arithmetic of the 1x1 contractions (upsamplers + head): "fp32" (exact, default), "bf16x3" (split-bf16, fp32-equivalent),
+        "bf16" (reduced-precision deploy mode).  Re-commits the loaded weights for the new tilings."""
+        if mode not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        _lib.check(self.lib.pp_set_precision(self.ctx, self.PRECISIONS[mode]), self.ctx, "pp_set_precision")
+        changed = mode != self.precision
+        self.precision = mode
+        if changed and self.weights_loaded:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.pp_commit_weights(self.ctx), self.ctx, "pp_commit_weights")
+
     def load_state_dict(self, sd):
         for k, v in sd.items():
             if k.endswith("num_batches_tracked"):

@@ -198,6 +198,8 @@ def main():
                     help="independent frames per pass per GPU (pp_infer_batch: frame = grid.z of the conv launches); weak scaling")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="TOTAL frames per step, sharded by frame index over the ranks (strong scaling; BASELINE config 5: 64)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the 1x1 contractions (pp_set_precision); anything but fp32 prints a TAGGED line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (stage rooflines, batch-1 latency, trained-like bias)")
@@ -249,7 +251,7 @@ def main():
     passes = [mine[i:i + MAXB] for i in range(0, NB, MAXB)] if NB else []
 
     def make_engine():
-        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=max(1, min(NB, MAXB)))
+        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=max(1, min(NB, MAXB)), **({} if stub else {"precision": args.precision}))
         e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
         return e
 
@@ -348,7 +350,7 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else args.precision,
             "data": "synthetic",
             "value_host_start": round(K * frames_per_step / elapsed_h, 3),
             "ms_per_step_host_start": round(elapsed_h / K * 1e3, 4),
@@ -369,6 +371,9 @@ def main():
                            "algorithmic_tflops": round(ach, 3),
                            "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
                                    "count in `algorithmic_*`)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+        if args.precision != "fp32":
+            out["tagged"] = (f"reduced-precision deploy mode '{args.precision}' of the 1x1 contractions (upsamplers + head; SURVEY 8(f).4): NOT the headline -- "
+                             "the headline is the fp32 line (dtype f32); tolerance table in DESIGN.md")
         if stub or (world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl"):
             out["rehearsal"] = "stub engine / ranks share devices, gather over gloo: not a measurement"
         if world == 1 and not args.no_extras and not stub:
