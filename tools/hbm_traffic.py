@@ -14,15 +14,17 @@ import os, csv, glob, json, re, sys
 
 def rows(d, counter):
     f = max(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
-    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and re.search(r'wino_mfma<[^>]*, 1>', r['Kernel_Name'])]
+    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and re.search(r'wino4?_mfma<[^>]*, 1>', r['Kernel_Name'])]
     if not rs:
-        raise SystemExit(f'no {counter} rows for the roofline copy wino_mfma<..., 1> in {f}')
+        raise SystemExit(f'no {counter} rows for the roofline copy wino(4)_mfma<..., 1> in {f}')
     vals = [float(r['Counter_Value']) for r in rs]
     return sum(vals) / len(vals), len(vals), rs[0]['Kernel_Name'].replace('(anonymous namespace)::', '')
 
 
 out, frames, alg = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
-res = {'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg, 'layer': 'conv 3x3 s1 64->64 @ 400x400',
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # source_hash(): ties the figures to the HIP sources they were taken on (bench.py drops them when it differs)
+res = {'source_hash': bench.source_hash(), 'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg, 'layer': 'conv 3x3 s1 64->64 @ 400x400',
        'unit': 'bytes', 'tilings': {}}
 for spec in sys.argv[4:]:
     name, dirs = spec.split('=')
