@@ -126,6 +126,9 @@ struct ConvP {
     const int32_t* pmap;
     const float* feat;
     size_t pmap_fs, feat_fs;
+    // wino4_mfma: the rectangle of output pixels this launch tiles (a layer whose map is not a multiple of the tile is
+    // covered by a main launch of whole tiles plus strip launches of thin tiles): origin, exclusive end, tiles in x / y
+    int rx0, ry0, rx1, ry1, rnbx, rnby;
 };
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
@@ -1091,6 +1094,7 @@ struct Wino4Cfg {
     {
         int v = IW;
         if (TWT == 16) return v;
+        if (TWT == 2 && BTX == 1) return 6; // 4 x 64 strip tile: rows 12 banks apart (0,12,24,4,...) keep a wave's 8 tile rows on distinct banks
         while ((2 * v) % 32 != TWT) ++v;
         return v;
     }
@@ -1134,7 +1138,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     const int wn = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
 
-    const int nbx = (p.Wout + C::PW - 1) / C::PW, nby = (p.Hout + C::PH - 1) / C::PH;
+    const int nbx = p.rnbx, nby = p.rnby; // tiles of this launch's region [rx0, rx1) x [ry0, ry1)
     const int ntile = nbx * nby, ncb = (p.Cout + C::BM - 1) / C::BM;
     const int total = ntile * ncb * p.nb;
     const int per = (total + 7) >> 3;
@@ -1164,7 +1168,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     unsigned r_vmask = 0u;
     auto set_load_tile = [&](int l) {
         const int cb_ = l % ncb, t_ = (l / ncb) % ntile, f_ = l / (ncb * ntile);
-        const int iy0_ = (t_ / nbx) * C::PH - 1, ix0_ = (t_ % nbx) * C::PW - 1;
+        const int iy0_ = p.ry0 + (t_ / nbx) * C::PH - 1, ix0_ = p.rx0 + (t_ % nbx) * C::PW - 1;
         vmask = 0u;
 #pragma unroll
         for (int r = 0; r < C::PR; ++r) {
@@ -1323,7 +1327,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         const int cb = lin % ncb, tile = (lin / ncb) % ntile;
         const size_t fz = lin / (ncb * ntile);
         const int co0 = cb * C::BM;
-        const int ox0 = (tile % nbx) * C::PW, oy0 = (tile / nbx) * C::PH;
+        const int ox0 = p.rx0 + (tile % nbx) * C::PW, oy0 = p.ry0 + (tile / nbx) * C::PH;
         const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
 
         // accumulator quad of (M-tile i, Winograd position xi): a[(xi*4 + i)*4 .. +3].  The tile's first 16 steps take 0 as C:
@@ -1452,8 +1456,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         if (!(p.dbg & 4)) {
         float* __restrict__ gout = p.out + fz * p.out_fs;
         const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
-        const bool pix_ok = (opx < p.Wout) && (opy < p.Hout);
-        const bool two_y = opy + 1 < p.Hout;
+        const bool pix_ok = (opx < p.rx1) && (opy < p.ry1); // pixels past the region's end belong to another launch (or to nobody)
+        const bool two_y = opy + 1 < p.ry1;
         const unsigned frame_bytes = (unsigned)((size_t)p.Cout * out_plane * 4);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(gout, 0, frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rres_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres ? gres : gout), 0, gres ? frame_bytes : 0u, 0x00020000);
@@ -1563,7 +1567,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             sum_p1_ += sh1_ - sh0_; sum_p2_ += sh2_ - sh1_;
 #endif
         };
-        if ((p.Wout & 3) == 0) {
+        if (((p.Wout | p.rx0 | p.rx1) & 3) == 0) {
             epilogue_half(std::integral_constant<int, 0>{}, std::true_type{});
             epilogue_half(std::integral_constant<int, 1>{}, std::true_type{});
         } else {
@@ -2547,6 +2551,11 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
     }
 }
 
+// wino4 strip tilings: a map that is not a multiple of the main tile (16x16 px) is covered by whole main tiles plus a right
+// strip of 4 x 64 px tiles and a bottom strip of 64 x 4 px tiles -- 100 x 100: 36 + 2 + 2 tiles instead of 49 mostly-empty ones
+static Variant& wino4_strip_v() { static Variant v = make_wino4<2, 1, 8>(false); return v; }  // 4 px wide, 64 px tall
+static Variant& wino4_strip_h() { static Variant v = make_wino4<16, 2, 8>(false); return v; } // 64 px wide, 4 px tall
+
 // cost model: wavefronts are dealt to 1024 SIMDs; a SIMD's time ~ (its wave count) x (tile pairs per wave).
 double model_cost(const Variant& v, int rows, int Hout, int Wout)
 {
@@ -2815,12 +2824,52 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         if (g < ncb) g = ncb;
         grid = dim3(g, 1, 1);
     }
-    if (v.wino == 4) { // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs
-        const int total = (int)grid.x * (int)grid.y * B;
-        int g = net->num_cu;
-        if (g > total) g = total;
-        g = (g + 7) & ~7;
-        grid = dim3(g, 1, 1);
+    if (v.wino == 4) {
+        // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs.
+        // Whole main tiles first; what they leave uncovered goes to strip launches of thin tiles when that needs fewer tiles
+        // than rounding the main grid up (same weight image: it depends on the 64-row block and the chunk only).
+        const bool tag4 = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
+        if (tag4) {
+            if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                hipEvent_t a, b;
+                PP_HIP(hipEventCreate(&a));
+                PP_HIP(hipEventCreate(&b));
+                ctx->prof_ev.push_back(a);
+                ctx->prof_ev.push_back(b);
+            }
+            ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0 * B;
+            PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used], stream));
+        }
+        const int ncb = pp_div_up(L.rows, v.bm);
+        auto launch_region = [&](const Variant& rv, int x0, int y0, int x1, int y1) {
+            ConvP q = p;
+            q.rx0 = x0; q.ry0 = y0; q.rx1 = x1; q.ry1 = y1;
+            q.rnbx = pp_div_up(x1 - x0, rv.pw); q.rnby = pp_div_up(y1 - y0, rv.ph);
+            const int total = q.rnbx * q.rnby * ncb * B;
+            int g = net->num_cu;
+            if (g > total) g = total;
+            g = (g + 7) & ~7;
+            hipLaunchKernelGGL(rv.kern, dim3(g), dim3(rv.threads), rv.lds, stream, q);
+        };
+        const int mw = (Wout / v.pw) * v.pw, mh = (Hout / v.ph) * v.ph;
+        const Variant &sv = wino4_strip_v(), &sh = wino4_strip_h();
+        const int full = pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph);
+        const int split = (mw / v.pw) * (mh / v.ph) + (Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0) +
+                          (Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0);
+        static const bool no_strips = getenv("PP_W4_STRIPS") && getenv("PP_W4_STRIPS")[0] == '0';
+        if (split < full && mw > 0 && mh > 0 && !no_strips) {
+            launch_region(v, 0, 0, mw, mh);
+            if (Wout > mw) launch_region(sv, mw, 0, Wout, Hout);
+            if (Hout > mh) launch_region(sh, 0, mh, mw, Hout);
+        } else {
+            launch_region(v, 0, 0, Wout, Hout);
+        }
+        if (tag4) {
+            PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], stream));
+            ctx->prof_used += 2;
+        }
+        PP_HIP(hipGetLastError());
+        return 0;
     }
     if (v.wino == 1) { // persistent Winograd: two workgroups per CU (LDS and registers allow exactly two), a multiple of the 8 XCDs
         const int total = (int)grid.x * (int)grid.y * B;
@@ -3071,6 +3120,8 @@ int pp_net_create(pp_ctx* ctx)
                                 pick_variant(2, 1, 1, head_rows(ctx->cfg.num_anchor_per_loc), H, W, ctx->cfg.num_anchor_per_loc == 9)});
     for (Layer& L : net->layers)
         PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
+    PP_HIP(hipFuncSetAttribute((const void*)wino4_strip_v().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_strip_v().lds));
+    PP_HIP(hipFuncSetAttribute((const void*)wino4_strip_h().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_strip_h().lds));
     return 0;
 }
 
