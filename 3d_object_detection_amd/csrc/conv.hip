@@ -1079,6 +1079,9 @@ __device__ __forceinline__ void w4_acc_read16(float (&v)[16])
 #else
 #define W4_PAD "s_nop 1\n\t"
 #endif
+#ifndef PP_W4_STORE_AUX
+#define PP_W4_STORE_AUX 0 // cache-policy bits of the epilogue's output stores (experiment: 2 = nt)
+#endif
 #ifndef PP_W4_DIAG
 #define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
 #endif
@@ -1279,6 +1282,10 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     const int rbase = (2 * tty) * C::IWP + ttx + kq * C::CS;
     const int aoff = kq * C::BM + m * 4;
 
+    // timing experiment (PP_CONV_DBG bits 8..): stagger the workgroups of an XCD by (dbg >> 8) x 512 cycles per phase, 8 phases:
+    // all CUs run tiles of equal length in lockstep, so their epilogues' stores hit the memory system as one burst
+    if (p.dbg >> 8)
+        for (int i = 0; i < (p.dbg >> 8) * (xj & 7); ++i) __builtin_amdgcn_s_sleep(8);
     // ---------------- pipeline prologue: chunks 0 and 1 into ring slots 0 and 1, chunk 2 into the registers ----------------
     set_load_tile(lin0);
     load_aff(s_frame);
@@ -1368,6 +1375,9 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                 asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" TAIL :: "v"(a[s_ % AD][I]), "v"(vcur), "i"((xi * 4 + I) * 4), "i"((xi * 4 + I) * 4 + 3) : W4_AGPRS); \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_W4_ALIGN
+            asm volatile(".p2align " PP_W4_ALIGN);
+#endif
             pp_steps<0, NSTEP>([&](auto S) {
                 constexpr int s_ = decltype(S)::value;
                 constexpr int c4 = s_ / 16, xi = s_ % 16;
@@ -1493,7 +1503,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                         // even lane: row y at its own pixels; odd lane: row y+1 starting at the even partner's pixels
                         const bool okq = ok && (par == 0 || two_y);
                         off0[ii][r] = okq ? (par ? o + (unsigned)p.Wout * 4u - 8u : o) : 0xFFFFFFFFu;
-                        rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0));
+                        rq[ii][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (gres) rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0)); // uniform: 7 of the 13 layers have no residual
                     } else {
                         off0[ii][r] = ok ? o : 0xFFFFFFFFu;
                         off1[ii][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
@@ -1533,7 +1544,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                         v[0] = par ? g0 : y[ii][r][0]; v[1] = par ? g1 : y[ii][r][1];
                         v[2] = par ? y[ii][r][2] : g0; v[3] = par ? y[ii][r][3] : g1;
                         v += rq[ii][r];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0u, 0, 0)), v), rout, off0[ii][r], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0u, 0, 0)), v), rout, off0[ii][r], 0, PP_W4_STORE_AUX);
                         const bool okq = off0[ii][r] != 0xFFFFFFFFu;
                         const float s_ = ((v[0] + v[1]) + v[2]) + v[3], q_ = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
                         ssum[r] = okq ? s_ : 0.f;
