@@ -1503,8 +1503,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                         // even lane: row y at its own pixels; odd lane: row y+1 starting at the even partner's pixels
                         const bool okq = ok && (par == 0 || two_y);
                         off0[ii][r] = okq ? (par ? o + (unsigned)p.Wout * 4u - 8u : o) : 0xFFFFFFFFu;
-                        rq[ii][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (gres) rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0)); // uniform: 7 of the 13 layers have no residual
+                        rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0)); // zero records when the layer has no residual
                     } else {
                         off0[ii][r] = ok ? o : 0xFFFFFFFFu;
                         off1[ii][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
@@ -2864,9 +2863,17 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         };
         const int mw = (Wout / v.pw) * v.pw, mh = (Hout / v.ph) * v.ph;
         const Variant &sv = wino4_strip_v(), &sh = wino4_strip_h();
-        const int full = pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph);
-        const int split = (mw / v.pw) * (mh / v.ph) + (Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0) +
-                          (Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0);
+        // cost of the slowest workgroup: items are dealt evenly over min(CUs, items) persistent workgroups, a tile takes about
+        // 2.4 us per 8-channel chunk + 5 us of epilogue, and a strip launch adds its own rounds plus ~30 us of launch gap and
+        // pipeline prologue (at batch 1 the 20 extra launches of a frame cost more than the empty tile area they save: 3.4 ms
+        // against 2.2 ms per frame; at 16+ frames per launch the strips win: 979 against 1114 us on the 100 x 100 layers)
+        auto rounds = [&](int tiles) { return tiles > 0 ? pp_div_up((int64_t)tiles * ncb * B, net->num_cu) : 0; };
+        const int t_main = (mw / v.pw) * (mh / v.ph);
+        const int t_right = Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0;
+        const int t_bottom = Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0;
+        const double tile_us = 2.4 * (L.cin / 8) + 5.0;
+        const double full = rounds(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph)) * tile_us;
+        const double split = (rounds(t_main) + rounds(t_right) + rounds(t_bottom)) * tile_us + 30.0 * ((t_right > 0) + (t_bottom > 0));
         static const bool no_strips = getenv("PP_W4_STRIPS") && getenv("PP_W4_STRIPS")[0] == '0';
         if (split < full && mw > 0 && mh > 0 && !no_strips) {
             launch_region(v, 0, 0, mw, mh);
