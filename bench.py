@@ -394,21 +394,30 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
     out = {}
     # batch=1 latency of this build (BASELINE config 2 is quoted at batch=1): one frame per pp_infer_frame call, synchronised
     # after every frame like train.py:236 -- resident cloud, and from pinned host memory
-    det1, cnt1 = eng.infer_frame(clouds[0])
-    torch.cuda.synchronize()
+    # -- with an engine of its own (max_batch = 1: the tuner then measures the tilings at ONE frame per launch, where smaller
+    # tiles win), as a batch-1 deployment would be built; `..._batch_engine` is the same through the 32-frame engine's tilings
+    eng1 = eng_mod.Engine(dict(cfg), device_index=local, max_batch=1)
+    eng1.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
     n = 30
-    for name, src in (("resident", clouds), ("host_start", host)):
-        t0 = time.perf_counter()
-        for i in range(n):
-            pts = src[i % len(src)]
-            if name == "host_start":
-                pts = pts.to(dev, non_blocking=True)
-            d, c = eng.infer_frame(pts, det1, cnt1)
-            c.cpu()
+    for tag, e in (("", eng1), ("_batch_engine", eng)):
+        det1, cnt1 = e.infer_frame(clouds[0])
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[f"batch1_latency_ms_{name}"] = round(dt / n * 1e3, 4)
-        out[f"batch1_frames_per_s_{name}"] = round(n / dt, 2)
+        for name, src in (("resident", clouds), ("host_start", host)):
+            if tag and name == "host_start":
+                continue
+            t0 = time.perf_counter()
+            for i in range(n):
+                pts = src[i % len(src)]
+                if name == "host_start":
+                    pts = pts.to(dev, non_blocking=True)
+                d, c = e.infer_frame(pts, det1, cnt1)
+                c.cpu()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"batch1_latency_ms_{name}{tag}"] = round(dt / n * 1e3, 4)
+            out[f"batch1_frames_per_s_{name}{tag}"] = round(n / dt, 2)
+    out["batch1_tilings"] = [L["tiling"] for L in eng1.layer_tilings()]
+    del eng1
     # the same resident pass with a trained-like head bias (few candidates instead of ~900 detections per frame)
     if args.cls_bias is None:
         eng.load_state_dict(synth.seeded_state_dict(0, cls_bias=-4.6))
