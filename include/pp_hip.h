@@ -112,7 +112,8 @@ int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, const float*
 int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream);
 
 /* nb <= cfg.max_batch independent frames in ONE pass: the conv/deconv/head launches carry the frame as grid.z
- * (per-frame InstanceNorm statistics; results identical to nb calls of pp_infer_frame), the small integer
+ * (per-frame InstanceNorm statistics; same detections as nb calls of pp_infer_frame, logits equal up to the
+ * fp32 summation order of those statistics, ~3e-5), the small integer
  * stages run per frame on the same stream.  pts_h / n_h: HOST arrays of nb device pointers / point counts.
  * det f32[nb][num_classes*nms_post_max][9], det_count i32[nb][PP_DET_COUNT_STRIDE] (total, then per class). */
 #define PP_DET_COUNT_STRIDE (1 + PP_MAX_CLASSES)
