@@ -1074,6 +1074,56 @@ __device__ __forceinline__ void w4_acc_read16(float (&v)[16])
                  : W4_AGPRS);
 }
 
+// rows R and R + 1 (R even) of M-tile I at the 16 Winograd positions, as 16 (row R, row R + 1) pairs for v_pk_* arithmetic:
+// position xi's quad starts at a[xi*16 + I*4]
+template <int I, int R>
+__device__ __forceinline__ void w4_acc_read32(float __attribute__((ext_vector_type(2))) (&v)[16])
+{
+    float l[16], u[16];
+    // operands %0..%15 = row R at position 0..15, %16..%31 = row R + 1 (operand numbers are spelled out: %1K would be ambiguous)
+    asm volatile("v_accvgpr_read_b32 %0, a[%c32+0]\n\tv_accvgpr_read_b32 %16, a[%c32+1]\n\t"
+                 "v_accvgpr_read_b32 %1, a[%c32+16]\n\tv_accvgpr_read_b32 %17, a[%c32+17]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%c32+32]\n\tv_accvgpr_read_b32 %18, a[%c32+33]\n\t"
+                 "v_accvgpr_read_b32 %3, a[%c32+48]\n\tv_accvgpr_read_b32 %19, a[%c32+49]\n\t"
+                 "v_accvgpr_read_b32 %4, a[%c32+64]\n\tv_accvgpr_read_b32 %20, a[%c32+65]\n\t"
+                 "v_accvgpr_read_b32 %5, a[%c32+80]\n\tv_accvgpr_read_b32 %21, a[%c32+81]\n\t"
+                 "v_accvgpr_read_b32 %6, a[%c32+96]\n\tv_accvgpr_read_b32 %22, a[%c32+97]\n\t"
+                 "v_accvgpr_read_b32 %7, a[%c32+112]\n\tv_accvgpr_read_b32 %23, a[%c32+113]\n\t"
+                 "v_accvgpr_read_b32 %8, a[%c32+128]\n\tv_accvgpr_read_b32 %24, a[%c32+129]\n\t"
+                 "v_accvgpr_read_b32 %9, a[%c32+144]\n\tv_accvgpr_read_b32 %25, a[%c32+145]\n\t"
+                 "v_accvgpr_read_b32 %10, a[%c32+160]\n\tv_accvgpr_read_b32 %26, a[%c32+161]\n\t"
+                 "v_accvgpr_read_b32 %11, a[%c32+176]\n\tv_accvgpr_read_b32 %27, a[%c32+177]\n\t"
+                 "v_accvgpr_read_b32 %12, a[%c32+192]\n\tv_accvgpr_read_b32 %28, a[%c32+193]\n\t"
+                 "v_accvgpr_read_b32 %13, a[%c32+208]\n\tv_accvgpr_read_b32 %29, a[%c32+209]\n\t"
+                 "v_accvgpr_read_b32 %14, a[%c32+224]\n\tv_accvgpr_read_b32 %30, a[%c32+225]\n\t"
+                 "v_accvgpr_read_b32 %15, a[%c32+240]\n\tv_accvgpr_read_b32 %31, a[%c32+241]"
+                 : "=v"(l[0]), "=v"(l[1]), "=v"(l[2]), "=v"(l[3]), "=v"(l[4]), "=v"(l[5]), "=v"(l[6]), "=v"(l[7]), "=v"(l[8]), "=v"(l[9]), "=v"(l[10]),
+                   "=v"(l[11]), "=v"(l[12]), "=v"(l[13]), "=v"(l[14]), "=v"(l[15]), "=v"(u[0]), "=v"(u[1]), "=v"(u[2]), "=v"(u[3]), "=v"(u[4]), "=v"(u[5]),
+                   "=v"(u[6]), "=v"(u[7]), "=v"(u[8]), "=v"(u[9]), "=v"(u[10]), "=v"(u[11]), "=v"(u[12]), "=v"(u[13]), "=v"(u[14]), "=v"(u[15])
+                 : "i"(I * 4 + R)
+                 : W4_AGPRS);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k][0] = l[k]; v[k][1] = u[k]; }
+}
+// Lanes 2j (tile x) and 2j+1 (tile x+1) hold the 2x2 outputs (y0 y1 / y2 y3) of neighbouring tiles.  Returns, in the even lane,
+// row y of both tiles (own y0 y1, partner's y0 y1) and in the odd lane row y+1 (partner's y2 y3, own y2 y3): v_cndmask_b32 with
+// its first source permuted over DPP (quad_perm [1,0,3,2] = lane ^ 1) -- 4 VALU instead of 2 selects + 2 DPP moves + 4 selects.
+// s_nop 1: a DPP source written by the VALU instruction before needs 2 wait states, and hipcc does not look inside asm.
+__device__ __forceinline__ f32x4 w4_pair_rows(float y0, float y1, float y2, float y3)
+{
+    float v0, v1, v2, v3;
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_nop 1\n\t"
+                 "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_not_b64 vcc, vcc\n\t"
+                 "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(y0), "v"(y1), "v"(y2), "v"(y3)
+                 : "vcc", "scc");
+    return (f32x4){v0, v1, v2, v3};
+}
+
 #if defined(PP_W4_DIAG) && (PP_W4_DIAG & 32)
 #define W4_PAD ""
 #else
@@ -1081,6 +1131,12 @@ __device__ __forceinline__ void w4_acc_read16(float (&v)[16])
 #endif
 #ifndef PP_W4_STORE_AUX
 #define PP_W4_STORE_AUX 0 // cache-policy bits of the epilogue's output stores (experiment: 2 = nt)
+#endif
+#ifndef PP_W4_RES_EARLY
+#define PP_W4_RES_EARLY 0 // 1: the first half's residual rows are requested at the top of the tile's last chunk (tried: the 32 registers they hold across the chunk spill)
+#endif
+#ifndef PP_W4_GAPS
+#define PP_W4_GAPS 2 // VALU gaps of the step loop: 0 = column pass in gap B, the rest in gap C; 1 = all in gap C (one VALU gap per step); 2 = one VALU gap per TWO steps
 #endif
 #ifndef PP_W4_DIAG
 #define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
@@ -1227,7 +1283,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     {                                                                                            \
         if constexpr ((E) < C::PR * KC) {                                                        \
             constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
-            xv[r_][c_] = fmaxf(fmaf(xv[r_][c_], SC[c_], SH[c_]), 0.f) * MASK[r_];               \
+            xv[r_][c_] = __builtin_amdgcn_fmed3f(fmaf(xv[r_][c_], SC[c_], SH[c_]), 0.f, MASK[r_]); /* MASK = +inf: ReLU; 0 (zero padding): 0 */ \
         }                                                                                        \
     }
 #define W4_READ_AFF(SC, SH, TAB, C0)                                                             \
@@ -1296,14 +1352,14 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         W4_READ_AFF(sc_, sh_, s_tab, s_ch * KC)
         float mk_[C::PR];
 #pragma unroll
-        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? 1.f : 0.f;
+        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? __builtin_inff() : 0.f;
         pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il, wl) });
         advance();
         __syncthreads(); // a new frame's table (if the second chunk is already there)
         pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
         W4_READ_AFF(sc_, sh_, s_tab, s_ch * KC)
 #pragma unroll
-        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? 1.f : 0.f;
+        for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? __builtin_inff() : 0.f;
         pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il + C::LDS_IN, wl + C::LDS_W) });
         advance();
         pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
@@ -1314,6 +1370,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     float draw[16], tq[2][16];
     f32x4 a[AD];
     float vcur, vnext;
+    float vb[4]; // PP_W4_GAPS == 2: B operands of steps s, s+1, s+2 (index = step & 3)
     // first operands of the very first chunk (later chunks get theirs during their predecessor's last steps)
     int qb = rbase;
     pp_steps<0, 4>([&](auto I) { W4_READ_RAW_ROW(draw, qb, decltype(I)::value) });
@@ -1321,6 +1378,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     for (int s0 = 0; s0 < AD - 1; ++s0) a[s0] = *reinterpret_cast<const f32x4*>(wl + (s0 * KC) * C::BM + aoff);
     pp_steps<0, 16>([&](auto K) { W4_COLPASS(tq[0], draw, decltype(K)::value) });
     vnext = W4_ROWPASS(tq[0], 0);
+    vb[0] = vnext; vb[1] = vb[2] = vb[3] = 0.f;
 
 #if PP_WINO_STAMP
     unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0, sum_p1_ = 0, sum_p2_ = 0;
@@ -1336,6 +1394,38 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         const int co0 = cb * C::BM;
         const int ox0 = p.rx0 + (tile % nbx) * C::PW, oy0 = p.ry0 + (tile / nbx) * C::PH;
         const int opx = ox0 + 2 * ttx, opy = oy0 + 2 * tty;
+
+        // Output / residual addressing of the epilogue (needed from the tile's LAST chunk on, which requests the first half's
+        // residual rows).  Offsets cost no VALU: the lane part (row co0 + 4 kq of the frame at this lane's pixels) is the
+        // instruction's VGPR offset, the (M-tile, accumulator row) part a wave-uniform multiple of the plane in its SGPR offset.
+        // Lanes with nothing to store start 2 GB out -- past any frame (launch_conv refuses larger ones) -- so the descriptor
+        // drops their accesses and returns zeros for their loads; a layer without a residual has a zero-record descriptor.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr unsigned W4_FAR = 0x80000000u;
+        const bool x4_map = ((p.Wout | p.rx0 | p.rx1) & 3) == 0;
+        const int par = m & 1;
+        const bool pix_ok = (opx < p.rx1) && (opy < p.ry1); // pixels past the region's end belong to another launch (or to nobody)
+        const bool two_y = opy + 1 < p.ry1;
+        const unsigned plane_ob = (unsigned)out_plane * 4u;
+        const unsigned rowb = (unsigned)(co0 + kq * 4) * plane_ob + (unsigned)(((size_t)opy * p.Wout + opx) * 4);
+        // x4 form: even lane = row y at its own pixels, odd lane = row y+1 starting at the even partner's pixels
+        const bool ok0 = x4_map ? (pix_ok && (par == 0 || two_y)) : pix_ok;
+        const unsigned lb0 = ok0 ? ((x4_map && par) ? rowb + (unsigned)p.Wout * 4u - 8u : rowb) : W4_FAR;
+        const unsigned lb1 = (pix_ok && two_y) ? rowb + (unsigned)p.Wout * 4u : W4_FAR; // second row of the dwordx2 form
+        f32x4 rq[2][2][4]; // residual rows [half][M-tile of the half][accumulator row] (x4 form)
+        auto res_desc = [&]() {
+            const float* gres = p.res ? p.res + fz * p.res_fs : p.out;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres), 0, p.res ? (unsigned)((size_t)p.Cout * out_plane * 4) : 0u, 0x00020000);
+        };
+        auto request_res = [&](auto HALF) { // 8 dwordx4 requests
+            constexpr int h = decltype(HALF)::value;
+            const __amdgpu_buffer_rsrc_t rres_ = res_desc();
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rq[h][ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, lb0, (unsigned)((h * 2 + ii) * 16 + r) * plane_ob, 0));
+        };
 
         // accumulator quad of (M-tile i, Winograd position xi): a[(xi*4 + i)*4 .. +3].  The tile's first 16 steps take 0 as C:
         // no zeroing pass over 256 registers; hence the chunk body exists twice (first chunk / accumulating chunks).
@@ -1354,11 +1444,14 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #endif
             float sc_[KC], sh_[KC];
             W4_READ_AFF(sc_, sh_, r_tab, r_c0)
-            float q_mask[C::PR]; // 1 inside the image, 0 on the zero padding (applied AFTER normalisation + ReLU)
+            float q_mask[C::PR]; // upper clamp of the normalised value: +inf inside the image, 0 on the zero padding (v_med3_f32 does ReLU and padding in one)
 #pragma unroll
-            for (int r = 0; r < C::PR; ++r) q_mask[r] = ((r_vmask >> r) & 1u) ? 1.f : 0.f;
+            for (int r = 0; r < C::PR; ++r) q_mask[r] = ((r_vmask >> r) & 1u) ? __builtin_inff() : 0.f;
             advance();
             r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
+            // the tile's last chunk: the first half's residual rows are requested a whole chunk before the epilogue adds them
+            // (from HBM under load they took 3-6 k cycles, which the epilogue had to wait out: stamps)
+            if constexpr (PP_W4_RES_EARLY) { if (ch == nchunk - 1 && x4_map) request_res(std::integral_constant<int, 0>{}); }
             WN_STAMP(st1_)
             // One wave per SIMD issues IN ORDER: whatever follows an MFMA waits for that MFMA to enter the matrix pipe, and four
             // MFMAs in a row leave the other instructions only the last one's 32 cycles (measured: the 32 steps took the SUM of
@@ -1381,7 +1474,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             pp_steps<0, NSTEP>([&](auto S) {
                 constexpr int s_ = decltype(S)::value;
                 constexpr int c4 = s_ / 16, xi = s_ % 16;
-                vcur = vnext;
+                if constexpr (PP_W4_GAPS == 2) vcur = vb[s_ & 3]; else vcur = vnext;
                 __builtin_amdgcn_sched_barrier(0);
                 W4_MFMA1(0, "")
                 if constexpr (!(PP_W4_DIAG & 4)) {   // gap A: A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
@@ -1405,7 +1498,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                     }
                     W4_READ_RAW_ROW(draw, qb, xi)
                 }
-                if constexpr (xi >= 6 && xi < 14) {
+                if constexpr (xi >= 6 && xi < 14 && !PP_W4_GAPS) {
                     if constexpr (PP_W4_DIAG & 1) {
                         tq[(c4 + 1) & 1][(xi - 6) * 2] = draw[(xi - 6) * 2];
                         tq[(c4 + 1) & 1][(xi - 6) * 2 + 1] = draw[(xi - 6) * 2 + 1];
@@ -1416,10 +1509,31 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 W4_MFMA1(2, "")
-                {   // gap C: row pass for step s_+1, normalisation of staging piece s_
+                if constexpr (PP_W4_GAPS == 2) {
+                    // gap C of the EVEN steps carries the VALU work of two steps (every MFMA -> VALU -> MFMA turn costs a lone wave
+                    // ~12 cycles on top of 4 per instruction, tools/issue_probe.hip): the B operands of steps s_+1 and s_+2 (row
+                    // pass), the normalisation of staging pieces s_ and s_+1, four column-pass terms of the next quad
+                    if constexpr ((s_ & 1) == 0) {
+                        constexpr int c4a = (s_ + 1) / 16, xia = (s_ + 1) % 16, c4b = (s_ + 2) / 16, xib = (s_ + 2) % 16;
+                        vb[(s_ + 1) & 3] = W4_ROWPASS(tq[c4a & 1], xia);
+                        vb[(s_ + 2) & 3] = W4_ROWPASS(tq[c4b & 1], xib);
+                        if constexpr (s_ < NPIECE) { W4_NORM_PIECE(s_, sc_, sh_, q_mask) }
+                        if constexpr (s_ + 1 < NPIECE) { W4_NORM_PIECE(s_ + 1, sc_, sh_, q_mask) }
+                        if constexpr (xi >= 6 && xi < 14) {
+                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
+                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
+                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 2)
+                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 3)
+                        }
+                    }
+                } else {   // gap C: row pass for step s_+1, normalisation of staging piece s_
                     constexpr int c4n = (s_ + 1) / 16, xin = (s_ + 1) % 16;
                     vnext = (PP_W4_DIAG & 1) ? tq[c4n & 1][xin] : W4_ROWPASS(tq[c4n & 1], xin);
                     if constexpr (s_ < NPIECE && !(PP_W4_DIAG & 16)) { W4_NORM_PIECE(s_, sc_, sh_, q_mask) }
+                    if constexpr (xi >= 6 && xi < 14 && PP_W4_GAPS) { // experiment: all VALU of a step in ONE gap
+                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
+                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The chunk's LAST MFMA carries the 12 wait states an 8-pass MFMA's D needs before anything but the next
@@ -1465,124 +1579,117 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #endif
         if (!(p.dbg & 4)) {
         float* __restrict__ gout = p.out + fz * p.out_fs;
-        const float* __restrict__ gres = p.res ? p.res + fz * p.res_fs : nullptr;
-        const bool pix_ok = (opx < p.rx1) && (opy < p.ry1); // pixels past the region's end belong to another launch (or to nobody)
-        const bool two_y = opy + 1 < p.ry1;
         const unsigned frame_bytes = (unsigned)((size_t)p.Cout * out_plane * 4);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(gout, 0, frame_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rres_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres ? gres : gout), 0, gres ? frame_bytes : 0u, 0x00020000);
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const unsigned pixb = (unsigned)(((size_t)opy * p.Wout + opx) * 4);
-        // Two halves (M-tiles 0-1, then 2-3), each in two phases.  Phase 1: request the half's residual rows (buffer descriptor:
-        // lanes without a pixel / row and layers without a residual get zero records), then the output transform of its 32
-        // (row, tile) pairs into registers -- no memory access, the residual rows land meanwhile.  Phase 2: ONE wait, then
-        // residual add, stores, statistics.  Loads and stores share vmcnt and may complete out of order with each other, so
-        // hipcc waits with vmcnt(0) for a load once a store is in flight: a residual add between two stores would wait for
-        // every store issued so far (~1 k cycles each).  Here the only such wait (second half) has a whole phase 1 behind the
-        // first half's stores.  The live state of the chunk pipeline (~130 VGPRs) leaves room for one half at a time.
+        // Two halves (M-tiles 0-1, then 2-3), each in two phases.  Phase 1: the output transform of the half's 32 (row, tile)
+        // pairs into registers, two accumulator rows at a time on v_pk_add_f32 (a lone wave pays 4 cycles per VALU instruction,
+        // MFMA shadow or not: tools/issue_probe.hip).  Phase 2: residual add, stores, statistics.  The residual rows are
+        // requested long before they are added: the first half's at the top of the tile's last chunk, the second half's
+        // between the first half's two phases -- older than every store of the epilogue, so waiting for them never waits for
+        // a store (loads and stores share vmcnt).  The live state of the chunk pipeline (~130 VGPRs) leaves room for both
+        // halves' residual rows and one half's outputs.
         // X4 (maps whose width is a multiple of 4): the tile's epilogue is bound by the CU's store ISSUE rate -- four waves x 32
         // dwordx2 stores of 4 x 128-byte segments each took ~11 k cycles per tile (stamps).  Neighbouring lanes (tiles x, x+1)
-        // swap half their 2x2 outputs over DPP so that the even lane owns row y and the odd lane row y+1 of the pair's 4
-        // pixels: one dwordx4 store (and one dwordx4 residual load) per lane and row instead of two dwordx2.
-        const int par = m & 1;
-        auto epilogue_half = [&](auto HALF, auto X4) {
-            constexpr int h = decltype(HALF)::value;
-            constexpr bool x4 = decltype(X4)::value;
-            unsigned off0[2][4], off1[2][4];
-            f32x2 r0[2][4], r1[2][4];
-            f32x4 rq[2][4];
-            float y[2][4][4];
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = co0 + (h * 2 + ii) * 16 + kq * 4 + r;
-                    const bool ok = pix_ok && row < p.Cout;
-                    const unsigned o = (unsigned)((size_t)row * out_plane * 4) + pixb;
-                    if constexpr (x4) {
-                        // even lane: row y at its own pixels; odd lane: row y+1 starting at the even partner's pixels
-                        const bool okq = ok && (par == 0 || two_y);
-                        off0[ii][r] = okq ? (par ? o + (unsigned)p.Wout * 4u - 8u : o) : 0xFFFFFFFFu;
-                        rq[ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, off0[ii][r], 0, 0)); // zero records when the layer has no residual
-                    } else {
-                        off0[ii][r] = ok ? o : 0xFFFFFFFFu;
-                        off1[ii][r] = (ok && two_y) ? o + (unsigned)p.Wout * 4u : 0xFFFFFFFFu;
-                        r0[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off0[ii][r], 0, 0));
-                        r1[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, off1[ii][r], 0, 0));
-                    }
-                }
+        // swap half their 2x2 outputs (w4_pair_rows: four v_cndmask_b32_dpp) so that the even lane owns row y and the odd lane
+        // row y+1 of the pair's 4 pixels: one dwordx4 store (and one dwordx4 residual load) per lane and row instead of two dwordx2.
+        f32x2 y2[2][2][4]; // [M-tile of the half][row pair][output pixel of the 2x2 tile], .x = row 2 rp, .y = row 2 rp + 1
 #if PP_WINO_STAMP
-            unsigned long long sh0_ = 0, sh1_ = 0, sh2_ = 0;
-            WN_STAMP(sh0_)
+        unsigned long long sh0_ = 0, sh1_ = 0;
 #endif
+        auto transform_half = [&](auto HALF) {
+            constexpr int h = decltype(HALF)::value;
+            WN_STAMP(sh0_)
             pp_steps<0, 2>([&](auto II) {
                 constexpr int ii = decltype(II)::value, i = h * 2 + ii;
-                pp_steps<0, 4>([&](auto R) {
-                    constexpr int r = decltype(R)::value;
-                    float mm[16], t0[4], t1[4];
-                    w4_acc_read16<i, r>(mm);
+                pp_steps<0, 2>([&](auto RP) {
+                    constexpr int rp = decltype(RP)::value;
+                    f32x2 mm[16], t0[4], t1[4];
+                    w4_acc_read32<i, 2 * rp>(mm);
 #pragma unroll
                     for (int a_ = 0; a_ < 4; ++a_) {
                         t0[a_] = mm[a_ * 4 + 0] + mm[a_ * 4 + 1] + mm[a_ * 4 + 2];
                         t1[a_] = mm[a_ * 4 + 1] - mm[a_ * 4 + 2] - mm[a_ * 4 + 3];
                     }
-                    y[ii][r][0] = t0[0] + t0[1] + t0[2]; y[ii][r][1] = t1[0] + t1[1] + t1[2];
-                    y[ii][r][2] = t0[1] - t0[2] - t0[3]; y[ii][r][3] = t1[1] - t1[2] - t1[3];
+                    y2[ii][rp][0] = t0[0] + t0[1] + t0[2]; y2[ii][rp][1] = t1[0] + t1[1] + t1[2];
+                    y2[ii][rp][2] = t0[1] - t0[2] - t0[3]; y2[ii][rp][3] = t1[1] - t1[2] - t1[3];
                 });
             });
             WN_STAMP(sh1_)
+#if PP_WINO_STAMP
+            sum_p1_ += sh1_ - sh0_;
+#endif
+        };
+        auto finish_half = [&](auto HALF, auto X4) {
+            constexpr int h = decltype(HALF)::value;
+            constexpr bool x4 = decltype(X4)::value;
+            WN_STAMP(sh0_)
+            f32x2 r0[2][4], r1[2][4];
+            if constexpr (!x4) { // maps whose width is not a multiple of 4: two dwordx2 rows per lane, requested here
+                const __amdgpu_buffer_rsrc_t rres_ = res_desc();
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned so = (unsigned)((h * 2 + ii) * 16 + r) * plane_ob;
+                        r0[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, lb0, so, 0));
+                        r1[ii][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres_, lb1, so, 0));
+                    }
+            }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 float ssum[4], ssq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const unsigned so = (unsigned)((h * 2 + ii) * 16 + r) * plane_ob;
+                    const float y_0 = y2[ii][r >> 1][0][r & 1], y_1 = y2[ii][r >> 1][1][r & 1], y_2 = y2[ii][r >> 1][2][r & 1], y_3 = y2[ii][r >> 1][3][r & 1];
                     if constexpr (x4) {
-                        const float s0 = par ? y[ii][r][0] : y[ii][r][2], s1 = par ? y[ii][r][1] : y[ii][r][3]; // what the partner needs of mine
-                        const float g0 = dpp_f32<0xB1>(s0), g1 = dpp_f32<0xB1>(s1);                               // quad_perm [1,0,3,2]: lane ^ 1
-                        f32x4 v;
-                        v[0] = par ? g0 : y[ii][r][0]; v[1] = par ? g1 : y[ii][r][1];
-                        v[2] = par ? y[ii][r][2] : g0; v[3] = par ? y[ii][r][3] : g1;
-                        v += rq[ii][r];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0u, 0, 0)), v), rout, off0[ii][r], 0, PP_W4_STORE_AUX);
-                        const bool okq = off0[ii][r] != 0xFFFFFFFFu;
-                        const float s_ = ((v[0] + v[1]) + v[2]) + v[3], q_ = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
-                        ssum[r] = okq ? s_ : 0.f;
-                        ssq[r] = okq ? q_ : 0.f;
+                        f32x4 v = w4_pair_rows(y_0, y_1, y_2, y_3);
+                        v += rq[h][ii][r];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0u, 0, 0)), v), rout, lb0, so, PP_W4_STORE_AUX);
+                        const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                        const f32x2 s2 = lo + hi, q2 = __builtin_elementwise_fma(hi, hi, lo * lo);
+                        ssum[r] = ok0 ? s2[0] + s2[1] : 0.f;
+                        ssq[r] = ok0 ? q2[0] + q2[1] : 0.f;
                     } else {
-                        const float y00 = y[ii][r][0] + r0[ii][r][0], y01 = y[ii][r][1] + r0[ii][r][1];
-                        const float y10 = y[ii][r][2] + r1[ii][r][0], y11 = y[ii][r][3] + r1[ii][r][1];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y00, y01}), rout, off0[ii][r], 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y10, y11}), rout, off1[ii][r], 0, 0);
-                        const bool ok0 = off0[ii][r] != 0xFFFFFFFFu, ok1 = off1[ii][r] != 0xFFFFFFFFu;
+                        const float y00 = y_0 + r0[ii][r][0], y01 = y_1 + r0[ii][r][1];
+                        const float y10 = y_2 + r1[ii][r][0], y11 = y_3 + r1[ii][r][1];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y00, y01}), rout, lb0, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rout, 0u, 0, 0)), (f32x2){y10, y11}), rout, lb1, so, 0);
                         float s_ = y00 + y01, q_ = y00 * y00 + y01 * y01; // same summation order as wino_mfma: row y, then row y+1
-                        if (ok1) { s_ += y10; q_ += y10 * y10; s_ += y11; q_ += y11 * y11; }
+                        if (lb1 != W4_FAR) { s_ += y10; q_ += y10 * y10; s_ += y11; q_ += y11 * y11; }
                         ssum[r] = ok0 ? s_ : 0.f;
                         ssq[r] = ok0 ? q_ : 0.f;
                     }
                 }
                 if (p.stat_acc) {
+                    float rs[4], rqq[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
-                        if (m == 0) {
-                            const int lr = (h * 2 + ii) * 16 + kq * 4 + r;
-                            red[(wn * C::BM + lr) * 2] = s;
-                            red[(wn * C::BM + lr) * 2 + 1] = q;
-                        }
+                    for (int r = 0; r < 4; ++r) { rs[r] = row16_sum(ssum[r]); rqq[r] = row16_sum(ssq[r]); }
+                    if (m == 0) { // rows (h*2+ii)*16 + kq*4 + 0..3: 8 consecutive floats of `red`
+                        float* dst = red + (wn * C::BM + (h * 2 + ii) * 16 + kq * 4) * 2;
+                        *reinterpret_cast<f32x4*>(dst) = (f32x4){rs[0], rqq[0], rs[1], rqq[1]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){rs[2], rqq[2], rs[3], rqq[3]};
                     }
                 }
             }
+            WN_STAMP(sh1_)
 #if PP_WINO_STAMP
-            WN_STAMP(sh2_)
-            sum_p1_ += sh1_ - sh0_; sum_p2_ += sh2_ - sh1_;
+            sum_p2_ += sh1_ - sh0_;
 #endif
         };
-        if (((p.Wout | p.rx0 | p.rx1) & 3) == 0) {
-            epilogue_half(std::integral_constant<int, 0>{}, std::true_type{});
-            epilogue_half(std::integral_constant<int, 1>{}, std::true_type{});
+        if (x4_map) {
+            if constexpr (!PP_W4_RES_EARLY) request_res(std::integral_constant<int, 0>{});
+            transform_half(std::integral_constant<int, 0>{});
+            if constexpr (PP_W4_RES_EARLY) request_res(std::integral_constant<int, 1>{});
+            finish_half(std::integral_constant<int, 0>{}, std::true_type{});
+            if constexpr (!PP_W4_RES_EARLY) request_res(std::integral_constant<int, 1>{});
+            transform_half(std::integral_constant<int, 1>{});
+            finish_half(std::integral_constant<int, 1>{}, std::true_type{});
         } else {
-            epilogue_half(std::integral_constant<int, 0>{}, std::false_type{});
-            epilogue_half(std::integral_constant<int, 1>{}, std::false_type{});
+            transform_half(std::integral_constant<int, 0>{});
+            finish_half(std::integral_constant<int, 0>{}, std::false_type{});
+            transform_half(std::integral_constant<int, 1>{});
+            finish_half(std::integral_constant<int, 1>{}, std::false_type{});
         }
         if (p.stat_acc) {
             pending = true;
@@ -2803,6 +2910,11 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     p.pre_inv_n = pre.inv_n; p.eps = 1e-3f;
     p.stat_acc = stat_acc; p.stat_C = stat_C;
     p.dbg_buf = g_stamp_buf;
+    {   // diagnostic builds: PP_STAMP_CIN / PP_STAMP_RES narrow the stamped layers (input channels; 0 / 1 = without / with residual)
+        static const char* sc = getenv("PP_STAMP_CIN");
+        static const char* sr = getenv("PP_STAMP_RES");
+        if ((sc && atoi(sc) != L.cin) || (sr && (atoi(sr) != 0) != (res != nullptr))) p.dbg_buf = nullptr;
+    }
     p.bias = (L.kind == 2 && L.var.wino == 3) ? net->head_bias_perm : net->head_bias; p.out_box = out_box; p.out_dir = out_dir;
     { const int na = ctx->cfg.num_anchor_per_loc; p.n_cls = na; p.n_box = 7 * na; p.n_rows = 10 * na; }
     { static const char* d = getenv("PP_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
@@ -2838,6 +2950,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs.
         // Whole main tiles first; what they leave uncovered goes to strip launches of thin tiles when that needs fewer tiles
         // than rounding the main grid up (same weight image: it depends on the 64-row block and the chunk only).
+        if ((size_t)L.rows * Hout * Wout * 4 >= 0x80000000ull) return PP_E_ARG; // the epilogue parks idle lanes' offsets 2 GB out (W4_FAR)
         const bool tag4 = ctx->prof_on && L.kind == 0 && L.level == 0 && L.stride == 1;
         if (tag4) {
             if (ctx->prof_used + 2 > ctx->prof_ev.size()) {

@@ -14,7 +14,7 @@ def main():
     pat = sys.argv[1]
     asm = sys.argv[2] if len(sys.argv) > 2 else "/tmp/conv.s"
     if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(SRC):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize",
                                "-munsafe-fp-atomics", "-S", "--cuda-device-only", SRC, "-o", asm] + os.environ.get("PP_EXTRA_FLAGS", "").split(),
                               stderr=subprocess.DEVNULL)
     s = open(asm).read()

@@ -1,0 +1,139 @@
+// Stand-alone probe (not part of the product): what can a CDNA4 SIMD issue next to v_mfma_f32_16x16x4_f32?
+// One workgroup on one CU, s_memtime around a loop of 8 independent MFMAs with N filler instructions behind each:
+//   one wave per SIMD (256 threads)      -- does a filler of the SAME wave hide in the MFMA's 32 cycles?
+//   two waves per SIMD (512 threads)     -- both run the same stream, or waves 4..7 run fillers only
+// hipcc --offload-arch=gfx950 -O3 tools/issue_probe.hip -o tools/_build/issue_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+#define MF(i) "v_mfma_f32_16x16x4_f32 %" #i ", %16, %17, %" #i "\n"
+// fillers: independent of each other and of the MFMAs
+#define VADD_A "v_add_f32 %8, %8, %17\n"
+#define VADD_B "v_add_f32 %9, %9, %17\n"
+#define VADD_C "v_add_f32 %10, %10, %17\n"
+#define VADD_D "v_add_f32 %11, %11, %17\n"
+#define VOWN_A "v_add_f32 %8, %8, %11\n"
+#define VOWN_B "v_add_f32 %9, %9, %11\n"
+#define VOWN_C "v_add_f32 %10, %10, %11\n"
+#define VMUL_A "v_mul_f32 %8, %8, %11\n"
+#define VFMA_A "v_fma_f32 %8, %8, %11, %11\n"
+#define VMAX_A "v_max_f32 %9, %9, %11\n"
+#define PK_A "v_pk_add_f32 %12, %12, %14\n"
+#define PK_B "v_pk_add_f32 %13, %13, %14\n"
+#define SADD "s_add_u32 s40, s40, 1\n"
+#define DSRD_A "ds_read_b32 %8, %18\n"
+#define DSRD_B "ds_read_b32 %9, %18 offset:256\n"
+#define DSRD4 "ds_read_b128 %15, %18 offset:1024\n"
+#define DSWR "ds_write_b32 %18, %10 offset:4096\n"
+#define VMOV "v_mov_b32 %11, %17\n"
+#define NOP0 "s_nop 0\n"
+
+#define BODY(F) MF(0) F MF(1) F MF(2) F MF(3) F MF(4) F MF(5) F MF(6) F MF(7) F "s_waitcnt lgkmcnt(0)\n"
+#define FILLONLY(F) F F F F F F F F "s_waitcnt lgkmcnt(0)\n"
+
+#define OPERANDS                                                                                                     \
+    : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), \
+      "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0)                                  \
+    : "v"(a), "v"(b), "v"(la)                                                                                        \
+    : "s40", "memory"
+
+// MODE 0: every wave runs BODY(F).  MODE 1: waves 0..3 run BODY("") (MFMA only), waves 4.. run FILLONLY(F) x 4.
+#define KERNEL(NAME, F)                                                                                              \
+    __global__ void __launch_bounds__(512) NAME(unsigned long long* out, int iters, int mode)                         \
+    {                                                                                                                \
+        __shared__ float lds[4096];                                                                                  \
+        f32x4 acc[8];                                                                                                \
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};                                            \
+        float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f, f0 = a, f1 = b, f2 = a, f3 = b;                      \
+        f32x2 p0 = {a, b}, p1 = {b, a}, p2 = {a, a};                                                                 \
+        f32x4 q0 = {a, b, a, b};                                                                                     \
+        lds[threadIdx.x] = a;                                                                                        \
+        unsigned la = (threadIdx.x & 63) * 4;                                                                        \
+        __syncthreads();                                                                                             \
+        const int wave = threadIdx.x >> 6;                                                                           \
+        unsigned long long t0 = __builtin_readcyclecounter();                                                        \
+        asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t0));                                               \
+        if (mode == 2 && wave < 4) {                                                                                 \
+        } else if (mode == 0 || wave < 4) {                                                                          \
+            if (mode == 0)                                                                                           \
+                for (int it = 0; it < iters; ++it) asm volatile(BODY(F) OPERANDS);                                   \
+            else                                                                                                     \
+                for (int it = 0; it < iters; ++it) asm volatile(BODY("") OPERANDS);                                  \
+        } else {                                                                                                     \
+            for (int it = 0; it < iters * 4; ++it) asm volatile(FILLONLY(F) OPERANDS);                               \
+        }                                                                                                            \
+        unsigned long long t1;                                                                                       \
+        asm volatile("s_nop 15\ns_nop 15\ns_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t1));                           \
+        float s = f0 + f1 + f2 + f3 + p0[0] + p1[0] + p2[1] + q0[0];                                                 \
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];                                                      \
+        if (s == 12345.678f) out[100] = 1;                                                                           \
+        if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;                                                            \
+    }
+
+KERNEL(k_none, "")
+KERNEL(k_vadd1, VADD_A)
+KERNEL(k_vadd2, VADD_A VADD_B)
+KERNEL(k_vadd4, VADD_A VADD_B VADD_C VADD_D)
+KERNEL(k_vadd6, VADD_A VADD_B VADD_C VADD_D VADD_A VADD_B)
+KERNEL(k_vown1, VOWN_A)
+KERNEL(k_vown2, VOWN_A VOWN_B)
+KERNEL(k_vown4, VOWN_A VOWN_B VOWN_C VOWN_A)
+KERNEL(k_vdep4, VOWN_A VOWN_A VOWN_A VOWN_A)
+KERNEL(k_vfma2, VFMA_A VMAX_A)
+KERNEL(k_vmul2, VMUL_A VMAX_A)
+KERNEL(k_pk1, PK_A)
+KERNEL(k_pk2, PK_A PK_B)
+KERNEL(k_pk4, PK_A PK_B PK_A PK_B)
+KERNEL(k_sadd1, SADD)
+KERNEL(k_sadd4, SADD SADD SADD SADD)
+KERNEL(k_nop4, NOP0 NOP0 NOP0 NOP0)
+KERNEL(k_vmov4, VMOV VMOV VMOV VMOV)
+KERNEL(k_dsrd1, DSRD_A)
+KERNEL(k_dsrd2, DSRD_A DSRD_B)
+KERNEL(k_dsrd4x1, DSRD4)
+KERNEL(k_dswr1, DSWR)
+KERNEL(k_mix, VADD_A DSRD_B VADD_C SADD)
+
+typedef void (*kfn)(unsigned long long*, int, int);
+struct Ent { const char* name; kfn f; int fillers; };
+
+int main()
+{
+    unsigned long long* out;
+    CK(hipMalloc(&out, 1024));
+    const int iters = 4000;
+    Ent ents[] = {{"none", k_none, 0}, {"v_add x1", k_vadd1, 1}, {"v_add x2", k_vadd2, 2}, {"v_add x4", k_vadd4, 4}, {"v_add x6", k_vadd6, 6},
+                  {"v_add own regs x1", k_vown1, 1}, {"v_add own regs x2", k_vown2, 2}, {"v_add own regs x4", k_vown4, 4}, {"v_add dependent x4", k_vdep4, 4},
+                  {"v_fma+v_max", k_vfma2, 2}, {"v_mul+v_max", k_vmul2, 2},
+                  {"v_pk_add x1", k_pk1, 1}, {"v_pk_add x2", k_pk2, 2}, {"v_pk_add x4", k_pk4, 4}, {"s_add x1", k_sadd1, 1}, {"s_add x4", k_sadd4, 4},
+                  {"s_nop x4", k_nop4, 4}, {"v_mov x4", k_vmov4, 4}, {"ds_read_b32 x1", k_dsrd1, 1}, {"ds_read_b32 x2", k_dsrd2, 2},
+                  {"ds_read_b128 x1", k_dsrd4x1, 1}, {"ds_write_b32 x1", k_dswr1, 1}, {"v_add+ds_read+v_add+s_add", k_mix, 4}};
+    printf("cycles per MFMA of the SLOWEST wave (v_mfma_f32_16x16x4_f32 = 32 cycles of matrix pipe), N fillers behind each MFMA; AGPR accumulators\n");
+    printf("A: one wave per SIMD.  B: two waves per SIMD, same stream (SIMD time per MFMA = B / 2).  C: waves 0-3 MFMA only, waves 4-7 fillers only:\n");
+    printf("MFMA wave cycles per MFMA | filler wave cycles per filler (alone: D)\n");
+    printf("%-28s %8s %8s %8s %8s | %6s %6s\n", "filler", "A", "B", "B/2", "C mfma", "C fill", "D fill");
+    for (const Ent& e : ents) {
+        double r[4] = {0, 0, 0, 0}, fill[2] = {0, 0};
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            const int threads = cfg == 0 ? 256 : 512, mode = cfg == 0 ? 0 : cfg - 1;
+            unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipMemset(out, 0, 64));
+                hipLaunchKernelGGL(e.f, dim3(1), dim3(threads), 0, 0, out, iters, mode);
+                CK(hipDeviceSynchronize());
+            }
+            CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+            unsigned long long m03 = 0, m47 = 0;
+            for (int w = 0; w < 4; ++w) { if (h[w] > m03) m03 = h[w]; if (h[w + 4] > m47) m47 = h[w + 4]; }
+            if (cfg <= 1) r[cfg] = (double)(m03 > m47 ? m03 : m47) / ((double)iters * 8);
+            if (cfg == 2) r[2] = (double)m03 / ((double)iters * 8);
+            if (cfg >= 2 && e.fillers) fill[cfg - 2] = (double)m47 / ((double)iters * 4 * 8 * e.fillers);
+        }
+        printf("%-28s %8.1f %8.1f %8.1f %8.1f | %6.1f %6.1f\n", e.name, r[0], r[1], r[1] / 2, r[2], fill[0], fill[1]);
+    }
+    return 0;
+}
