@@ -1105,6 +1105,13 @@ __device__ __forceinline__ void w4_acc_read32(float __attribute__((ext_vector_ty
 #pragma unroll
     for (int k = 0; k < 16; ++k) { v[k][0] = l[k]; v[k][1] = u[k]; }
 }
+// Row pass of the Winograd input transform, middle positions: tb = (t1, t3), ta = (t0, t2) of one row of B^T d  ->  (t1 + t2, t2 - t1)
+__device__ __forceinline__ float __attribute__((ext_vector_type(2))) w4_row_mid(float __attribute__((ext_vector_type(2))) tb, float __attribute__((ext_vector_type(2))) ta)
+{
+    float __attribute__((ext_vector_type(2))) r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(tb), "v"(ta));
+    return r;
+}
 // Lanes 2j (tile x) and 2j+1 (tile x+1) hold the 2x2 outputs (y0 y1 / y2 y3) of neighbouring tiles.  Returns, in the even lane,
 // row y of both tiles (own y0 y1, partner's y0 y1) and in the odd lane row y+1 (partner's y2 y3, own y2 y3): v_cndmask_b32 with
 // its first source permuted over DPP (quad_perm [1,0,3,2] = lane ^ 1) -- 4 VALU instead of 2 selects + 2 DPP moves + 4 selects.
@@ -1134,9 +1141,6 @@ __device__ __forceinline__ f32x4 w4_pair_rows(float y0, float y1, float y2, floa
 #endif
 #ifndef PP_W4_RES_EARLY
 #define PP_W4_RES_EARLY 0 // 1: the first half's residual rows are requested at the top of the tile's last chunk (tried: the 32 registers they hold across the chunk spill)
-#endif
-#ifndef PP_W4_GAPS
-#define PP_W4_GAPS 2 // VALU gaps of the step loop: 0 = column pass in gap B, the rest in gap C; 1 = all in gap C (one VALU gap per step); 2 = one VALU gap per TWO steps
 #endif
 #ifndef PP_W4_DIAG
 #define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
@@ -1214,7 +1218,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, 0x7FFFFFFF, 0x00020000);
     const unsigned plane_b = (unsigned)(p.Hin * p.Win) * 4u;
     unsigned wbase_b = 0u;
-    float xv[C::PR][KC];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 xv[C::PR][KC / 2]; // staging registers: channel pairs (2k, 2k+1), so one v_pk_fma_f32 normalises two pieces
     f32x4 wv[C::WR];
 #pragma unroll
     for (int r = 0; r < C::PR; ++r) {
@@ -1272,18 +1277,21 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     {                                                                                            \
         if constexpr ((E) < C::PR * KC) {                                                        \
             constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
-            xv[r_][c_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[r_], (unsigned)(s_ch * KC + c_) * plane_b, 0)); \
+            xv[r_][c_ / 2][c_ & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, goff[r_], (unsigned)(s_ch * KC + c_) * plane_b, 0)); \
         } else if constexpr ((E) < C::PR * KC + C::WR) {                                         \
             constexpr int r_ = (E) - C::PR * KC;                                                 \
             wv[r_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + r_ * C::THREADS) * 16, wbase_b + (unsigned)s_ch * (C::W4 * 16), 0)); \
         }                                                                                        \
     }
-// normalise + ReLU + zero padding of input piece E in place (SC/SH: this chunk's KC scales / shifts, MASK: its in-image bits)
-#define W4_NORM_PIECE(E, SC, SH, MASK)                                                           \
+// normalise + ReLU + zero padding of input pieces E, E+1 (E even: one channel pair) in place.  SC/SH: this chunk's KC scales /
+// shifts, MASK: upper clamp per position (+inf inside the image = plain ReLU, 0 on the zero padding) -- v_pk_fma_f32 + 2 v_med3_f32
+#define W4_NORM_PAIR(E, SC, SH, MASK)                                                            \
     {                                                                                            \
-        if constexpr ((E) < C::PR * KC) {                                                        \
+        if constexpr ((E) < C::PR * KC && (E) % 2 == 0) {                                        \
             constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
-            xv[r_][c_] = __builtin_amdgcn_fmed3f(fmaf(xv[r_][c_], SC[c_], SH[c_]), 0.f, MASK[r_]); /* MASK = +inf: ReLU; 0 (zero padding): 0 */ \
+            const f32x2 t_ = __builtin_elementwise_fma(xv[r_][c_ / 2], (f32x2){SC[c_], SC[c_ + 1]}, (f32x2){SH[c_], SH[c_ + 1]}); \
+            xv[r_][c_ / 2][0] = __builtin_amdgcn_fmed3f(t_[0], 0.f, MASK[r_]);                   \
+            xv[r_][c_ / 2][1] = __builtin_amdgcn_fmed3f(t_[1], 0.f, MASK[r_]);                   \
         }                                                                                        \
     }
 #define W4_READ_AFF(SC, SH, TAB, C0)                                                             \
@@ -1299,32 +1307,35 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     {                                                                                            \
         if constexpr ((E) < C::PR * KC) {                                                        \
             constexpr int r_ = (E) / KC, c_ = (E) % KC;                                          \
-            (IB)[c_ * C::CS + loff[r_]] = xv[r_][c_];                                            \
+            (IB)[c_ * C::CS + loff[r_]] = xv[r_][c_ / 2][c_ & 1];                                \
         } else if constexpr ((E) < C::PR * KC + C::WR) {                                         \
             constexpr int r_ = (E) - C::PR * KC;                                                 \
             reinterpret_cast<f32x4*>(WB)[tid + r_ * C::THREADS] = wv[r_];                        \
         }                                                                                        \
     }
-#define W4_READ_RAW(DST, IB, C4)                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                         \
-            DST[i_ * 4 + j_] = (IB)[rbase + (C4) * 4 * C::CS + i_ * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
 // one row (4 values) of the raw 4x4 patch of the quad whose element index inside the ring is QB.  QB is made opaque once per
 // quad: otherwise hipcc folds the quad's offset into every row address and spends a v_add per ds_read2 on constants that no
 // longer fit the instruction's 8-bit offsets (the row offsets alone do: <= 3*IWP + HALF + 1 dwords)
 #define W4_READ_RAW_ROW(DST, QB, I)                                                              \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                             \
-        DST[(I) * 4 + j_] = il[(QB) + (I) * C::IWP + (j_ & 1) * C::HALF + (j_ >> 1)];
-#define W4_COLPASS(T, D, K)                                                                      \
     {                                                                                            \
-        constexpr int a_ = (K) / 4, j_ = (K) % 4;                                                \
-        if constexpr (a_ == 0) T[0 + j_] = D[0 + j_] - D[8 + j_];                                \
-        else if constexpr (a_ == 1) T[4 + j_] = D[4 + j_] + D[8 + j_];                           \
-        else if constexpr (a_ == 2) T[8 + j_] = D[8 + j_] - D[4 + j_];                           \
-        else T[12 + j_] = D[4 + j_] - D[12 + j_];                                                \
+        DST[(I) * 2] = (f32x2){il[(QB) + (I) * C::IWP], il[(QB) + (I) * C::IWP + 1]};            \
+        DST[(I) * 2 + 1] = (f32x2){il[(QB) + (I) * C::IWP + C::HALF], il[(QB) + (I) * C::IWP + C::HALF + 1]}; \
     }
-#define W4_ROWPASS(T, XI)                                                                        \
-    (((XI) & 3) == 0 ? T[(XI)] - T[((XI) + 2) & 15] : ((XI) & 3) == 1 ? T[(XI)] + T[((XI) + 1) & 15] : ((XI) & 3) == 2 ? T[(XI)] - T[((XI) - 1) & 15] : T[((XI) - 2) & 15] - T[(XI)])
+// Input transform V = B^T d B on column PAIRS: the patch rows sit in LDS with even and odd columns de-interleaved, so a row is
+// two ds_read2_b32 = the register pairs (d0, d2) and (d1, d3).  Packed arithmetic because a lone wave pays 4 cycles per VALU
+// instruction, MFMA shadow or not (tools/issue_probe.hip).
+// column pass, term K2 = 2*row + pair of T = B^T d (rows of pairs TA = (t0, t2), TB = (t1, t3)):
+#define W4_COLPASS2(T, D, K2)                                                                    \
+    {                                                                                            \
+        constexpr int a_ = (K2) / 2, h_ = (K2) % 2;                                              \
+        if constexpr (a_ == 0) T[0 + h_] = D[0 + h_] - D[4 + h_];                                \
+        else if constexpr (a_ == 1) T[2 + h_] = D[2 + h_] + D[4 + h_];                           \
+        else if constexpr (a_ == 2) T[4 + h_] = D[4 + h_] - D[2 + h_];                           \
+        else T[6 + h_] = D[2 + h_] - D[6 + h_];                                                  \
+    }
+// row pass of row A: positions 4A .. 4A+3 = t0 - t2 | (t1 + t2, t2 - t1) in one v_pk_add_f32 | t1 - t3
+#define W4_ROW_FIRST(T, A) { o0 = T[(A) * 2][0] - T[(A) * 2][1]; p12[(A) & 1] = w4_row_mid(T[(A) * 2 + 1], T[(A) * 2]); }
+#define W4_ROW_LAST(T, A) { o3 = T[(A) * 2 + 1][0] - T[(A) * 2 + 1][1]; }
 
     constexpr int NQ = KC / 4;                // 2
     constexpr int NSTEP = NQ * 16;            // 32 steps of 4 MFMAs
@@ -1353,32 +1364,33 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         float mk_[C::PR];
 #pragma unroll
         for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? __builtin_inff() : 0.f;
-        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il, wl) });
+        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PAIR(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il, wl) });
         advance();
         __syncthreads(); // a new frame's table (if the second chunk is already there)
         pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
         W4_READ_AFF(sc_, sh_, s_tab, s_ch * KC)
 #pragma unroll
         for (int r = 0; r < C::PR; ++r) mk_[r] = ((vmask >> r) & 1u) ? __builtin_inff() : 0.f;
-        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PIECE(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il + C::LDS_IN, wl + C::LDS_W) });
+        pp_steps<0, NPIECE>([&](auto E) { W4_NORM_PAIR(decltype(E)::value, sc_, sh_, mk_) W4_WRITE_PIECE(decltype(E)::value, il + C::LDS_IN, wl + C::LDS_W) });
         advance();
         pp_steps<0, NPIECE>([&](auto E) { W4_LOAD_PIECE(decltype(E)::value) });
         r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
     }
     __syncthreads();
 
-    float draw[16], tq[2][16];
+    f32x2 draw[8], tq[2][8]; // raw 4x4 patch and its column pass, as column pairs [row][pair]
     f32x4 a[AD];
-    float vcur, vnext;
-    float vb[4]; // PP_W4_GAPS == 2: B operands of steps s, s+1, s+2 (index = step & 3)
+    float vcur;
+    float o0, o3 = 0.f;      // B operands of the steps 4A (o0), 4A+1 / 4A+2 (p12[A & 1]) and 4A+3 (o3) of patch row A
+    f32x2 p12[2];
     // first operands of the very first chunk (later chunks get theirs during their predecessor's last steps)
     int qb = rbase;
     pp_steps<0, 4>([&](auto I) { W4_READ_RAW_ROW(draw, qb, decltype(I)::value) });
 #pragma unroll
     for (int s0 = 0; s0 < AD - 1; ++s0) a[s0] = *reinterpret_cast<const f32x4*>(wl + (s0 * KC) * C::BM + aoff);
-    pp_steps<0, 16>([&](auto K) { W4_COLPASS(tq[0], draw, decltype(K)::value) });
-    vnext = W4_ROWPASS(tq[0], 0);
-    vb[0] = vnext; vb[1] = vb[2] = vb[3] = 0.f;
+    pp_steps<0, 8>([&](auto K) { W4_COLPASS2(tq[0], draw, decltype(K)::value) });
+    p12[1] = (f32x2){0.f, 0.f};
+    W4_ROW_FIRST(tq[0], 0)
 
 #if PP_WINO_STAMP
     unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0, sum_p1_ = 0, sum_p2_ = 0;
@@ -1400,7 +1412,6 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         // instruction's VGPR offset, the (M-tile, accumulator row) part a wave-uniform multiple of the plane in its SGPR offset.
         // Lanes with nothing to store start 2 GB out -- past any frame (launch_conv refuses larger ones) -- so the descriptor
         // drops their accesses and returns zeros for their loads; a layer without a residual has a zero-record descriptor.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         constexpr unsigned W4_FAR = 0x80000000u;
         const bool x4_map = ((p.Wout | p.rx0 | p.rx1) & 3) == 0;
         const int par = m & 1;
@@ -1474,7 +1485,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             pp_steps<0, NSTEP>([&](auto S) {
                 constexpr int s_ = decltype(S)::value;
                 constexpr int c4 = s_ / 16, xi = s_ % 16;
-                if constexpr (PP_W4_GAPS == 2) vcur = vb[s_ & 3]; else vcur = vnext;
+                vcur = (xi & 3) == 0 ? o0 : (xi & 3) == 3 ? o3 : p12[(xi >> 2) & 1][(xi & 3) - 1];
                 __builtin_amdgcn_sched_barrier(0);
                 W4_MFMA1(0, "")
                 if constexpr (!(PP_W4_DIAG & 4)) {   // gap A: A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
@@ -1498,41 +1509,18 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                     }
                     W4_READ_RAW_ROW(draw, qb, xi)
                 }
-                if constexpr (xi >= 6 && xi < 14 && !PP_W4_GAPS) {
-                    if constexpr (PP_W4_DIAG & 1) {
-                        tq[(c4 + 1) & 1][(xi - 6) * 2] = draw[(xi - 6) * 2];
-                        tq[(c4 + 1) & 1][(xi - 6) * 2 + 1] = draw[(xi - 6) * 2 + 1];
-                    } else {
-                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
-                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 W4_MFMA1(2, "")
-                if constexpr (PP_W4_GAPS == 2) {
-                    // gap C of the EVEN steps carries the VALU work of two steps (every MFMA -> VALU -> MFMA turn costs a lone wave
-                    // ~12 cycles on top of 4 per instruction, tools/issue_probe.hip): the B operands of steps s_+1 and s_+2 (row
-                    // pass), the normalisation of staging pieces s_ and s_+1, four column-pass terms of the next quad
-                    if constexpr ((s_ & 1) == 0) {
-                        constexpr int c4a = (s_ + 1) / 16, xia = (s_ + 1) % 16, c4b = (s_ + 2) / 16, xib = (s_ + 2) % 16;
-                        vb[(s_ + 1) & 3] = W4_ROWPASS(tq[c4a & 1], xia);
-                        vb[(s_ + 2) & 3] = W4_ROWPASS(tq[c4b & 1], xib);
-                        if constexpr (s_ < NPIECE) { W4_NORM_PIECE(s_, sc_, sh_, q_mask) }
-                        if constexpr (s_ + 1 < NPIECE) { W4_NORM_PIECE(s_ + 1, sc_, sh_, q_mask) }
-                        if constexpr (xi >= 6 && xi < 14) {
-                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
-                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
-                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 2)
-                            W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 3)
-                        }
-                    }
-                } else {   // gap C: row pass for step s_+1, normalisation of staging piece s_
-                    constexpr int c4n = (s_ + 1) / 16, xin = (s_ + 1) % 16;
-                    vnext = (PP_W4_DIAG & 1) ? tq[c4n & 1][xin] : W4_ROWPASS(tq[c4n & 1], xin);
-                    if constexpr (s_ < NPIECE && !(PP_W4_DIAG & 16)) { W4_NORM_PIECE(s_, sc_, sh_, q_mask) }
-                    if constexpr (xi >= 6 && xi < 14 && PP_W4_GAPS) { // experiment: all VALU of a step in ONE gap
-                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2)
-                        W4_COLPASS(tq[(c4 + 1) & 1], draw, (xi - 6) * 2 + 1)
+                // gap C of the EVEN steps carries the VALU work of two steps (every MFMA -> VALU -> MFMA turn costs a lone wave
+                // ~12 cycles on top of 4 per instruction, tools/issue_probe.hip), all of it packed: the B operands of steps s_+2 and
+                // s_+3 (row pass: 3 instructions per 4 steps), the normalisation of staging pieces s_ and s_+1, two column-pass terms of the next quad
+                if constexpr ((s_ & 1) == 0) {
+                    constexpr int sn = s_ + 2, c4n = sn / 16, xin = sn % 16;
+                    if constexpr ((xin & 3) == 0) { W4_ROW_FIRST(tq[c4n & 1], xin / 4) } else { W4_ROW_LAST(tq[c4n & 1], xin / 4) }
+                    if constexpr (!(PP_W4_DIAG & 16)) { W4_NORM_PAIR(s_, sc_, sh_, q_mask) }
+                    if constexpr (xi >= 6 && xi < 14) {
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 6)
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 6 + 1)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1721,13 +1709,13 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         }
     }
 #undef W4_LOAD_PIECE
-#undef W4_NORM_PIECE
+#undef W4_NORM_PAIR
 #undef W4_READ_AFF
 #undef W4_READ_RAW_ROW
 #undef W4_WRITE_PIECE
-#undef W4_READ_RAW
-#undef W4_COLPASS
-#undef W4_ROWPASS
+#undef W4_COLPASS2
+#undef W4_ROW_FIRST
+#undef W4_ROW_LAST
 }
 
 // ------------------------------------------------------------------------------------------
