@@ -1333,9 +1333,13 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         else if constexpr (a_ == 2) T[4 + h_] = D[4 + h_] - D[2 + h_];                           \
         else T[6 + h_] = D[2 + h_] - D[6 + h_];                                                  \
     }
-// row pass of row A: positions 4A .. 4A+3 = t0 - t2 | (t1 + t2, t2 - t1) in one v_pk_add_f32 | t1 - t3
-#define W4_ROW_FIRST(T, A) { o0 = T[(A) * 2][0] - T[(A) * 2][1]; p12[(A) & 1] = w4_row_mid(T[(A) * 2 + 1], T[(A) * 2]); }
-#define W4_ROW_LAST(T, A) { o3 = T[(A) * 2 + 1][0] - T[(A) * 2 + 1][1]; }
+// row pass of patch row A: the B operands of steps 4A .. 4A+3 = t0 - t2 | (t1 + t2, t2 - t1) in one v_pk_add_f32 | t1 - t3
+#define W4_ROW_ALL(T, A)                                                                         \
+    {                                                                                            \
+        o0[(A) & 1] = T[((A) & 3) * 2][0] - T[((A) & 3) * 2][1];                                 \
+        p12[(A) & 1] = w4_row_mid(T[((A) & 3) * 2 + 1], T[((A) & 3) * 2]);                       \
+        o3[(A) & 1] = T[((A) & 3) * 2 + 1][0] - T[((A) & 3) * 2 + 1][1];                         \
+    }
 
     constexpr int NQ = KC / 4;                // 2
     constexpr int NSTEP = NQ * 16;            // 32 steps of 4 MFMAs
@@ -1381,7 +1385,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     f32x2 draw[8], tq[2][8]; // raw 4x4 patch and its column pass, as column pairs [row][pair]
     f32x4 a[AD];
     float vcur;
-    float o0, o3 = 0.f;      // B operands of the steps 4A (o0), 4A+1 / 4A+2 (p12[A & 1]) and 4A+3 (o3) of patch row A
+    float o0[2], o3[2];      // B operands of the steps 4A (o0), 4A+1 / 4A+2 (p12) and 4A+3 (o3) of patch row A: slot A & 1
     f32x2 p12[2];
     // first operands of the very first chunk (later chunks get theirs during their predecessor's last steps)
     int qb = rbase;
@@ -1389,8 +1393,9 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #pragma unroll
     for (int s0 = 0; s0 < AD - 1; ++s0) a[s0] = *reinterpret_cast<const f32x4*>(wl + (s0 * KC) * C::BM + aoff);
     pp_steps<0, 8>([&](auto K) { W4_COLPASS2(tq[0], draw, decltype(K)::value) });
+    o0[1] = o3[1] = 0.f;
     p12[1] = (f32x2){0.f, 0.f};
-    W4_ROW_FIRST(tq[0], 0)
+    W4_ROW_ALL(tq[0], 0)
 
 #if PP_WINO_STAMP
     unsigned long long sum_pre_ = 0, sum_steps_ = 0, sum_bar_ = 0, sum_epi_ = 0, n_chunks_ = 0, n_tiles_ = 0, sum_p1_ = 0, sum_p2_ = 0;
@@ -1471,12 +1476,37 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             //   gap C: row pass of step s+1's B operand, normalise piece s  gap D: LDS write of piece s + the request that refills it
             // (<= 24 issue cycles per gap hide under the 32-cycle MFMA).  A B operand is written two gaps before its first use and
             // the A fragments come from LDS behind hipcc's own lgkmcnt wait, so the asm MFMAs need no s_nop pad.
-#define W4_MFMA1(I, TAIL)                                                                        \
+// N MFMAs of one step (M-tiles I .. I+N-1) in ONE asm statement: hipcc pads every boundary between two asm statements
+// with an s_nop, so MFMAs with nothing to put between them are issued from one statement
+#define W4_ACC(I) "i"((xi * 4 + (I)) * 4), "i"((xi * 4 + (I)) * 4 + 3)
+#define W4_MFMA_1(I)                                                                             \
             if constexpr (PP_W4_DIAG & 8) { asm volatile("" ::"v"(a[s_ % AD][I]), "v"(vcur)); }   \
             else if constexpr (first_ && s_ < 16) {                                              \
-                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" TAIL :: "v"(a[s_ % AD][I]), "v"(vcur), "i"((xi * 4 + I) * 4), "i"((xi * 4 + I) * 4 + 3) : W4_AGPRS); \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" :: "v"(a[s_ % AD][I]), "v"(vcur), W4_ACC(I) : W4_AGPRS); \
             } else {                                                                             \
-                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" TAIL :: "v"(a[s_ % AD][I]), "v"(vcur), "i"((xi * 4 + I) * 4), "i"((xi * 4 + I) * 4 + 3) : W4_AGPRS); \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a[s_ % AD][I]), "v"(vcur), W4_ACC(I) : W4_AGPRS); \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
+#define W4_MFMA_2(I)                                                                             \
+            if constexpr (PP_W4_DIAG & 8) { asm volatile("" ::"v"(a[s_ % AD][I]), "v"(vcur)); }   \
+            else if constexpr (first_ && s_ < 16) {                                              \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c3:%c4], %0, %2, 0\n\tv_mfma_f32_16x16x4_f32 a[%c5:%c6], %1, %2, 0"                  \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(vcur), W4_ACC(I), W4_ACC((I) + 1) : W4_AGPRS); \
+            } else {                                                                             \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c3:%c4], %0, %2, a[%c3:%c4]\n\tv_mfma_f32_16x16x4_f32 a[%c5:%c6], %1, %2, a[%c5:%c6]" \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(vcur), W4_ACC(I), W4_ACC((I) + 1) : W4_AGPRS); \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
+#define W4_MFMA_3(I)                                                                             \
+            if constexpr (PP_W4_DIAG & 8) { asm volatile("" ::"v"(a[s_ % AD][I]), "v"(vcur)); }   \
+            else if constexpr (first_ && s_ < 16) {                                              \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c4:%c5], %0, %3, 0\n\tv_mfma_f32_16x16x4_f32 a[%c6:%c7], %1, %3, 0\n\t"            \
+                             "v_mfma_f32_16x16x4_f32 a[%c8:%c9], %2, %3, 0"                                                                 \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(a[s_ % AD][(I) + 2]), "v"(vcur), W4_ACC(I), W4_ACC((I) + 1), W4_ACC((I) + 2) : W4_AGPRS); \
+            } else {                                                                             \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c4:%c5], %0, %3, a[%c4:%c5]\n\tv_mfma_f32_16x16x4_f32 a[%c6:%c7], %1, %3, a[%c6:%c7]\n\t" \
+                             "v_mfma_f32_16x16x4_f32 a[%c8:%c9], %2, %3, a[%c8:%c9]"                                                        \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(a[s_ % AD][(I) + 2]), "v"(vcur), W4_ACC(I), W4_ACC((I) + 1), W4_ACC((I) + 2) : W4_AGPRS); \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);
 #ifdef PP_W4_ALIGN
@@ -1484,10 +1514,12 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #endif
             pp_steps<0, NSTEP>([&](auto S) {
                 constexpr int s_ = decltype(S)::value;
-                constexpr int c4 = s_ / 16, xi = s_ % 16;
-                vcur = (xi & 3) == 0 ? o0 : (xi & 3) == 3 ? o3 : p12[(xi >> 2) & 1][(xi & 3) - 1];
+                constexpr int c4 = s_ / 16, xi = s_ % 16, row = s_ / 4;
+                constexpr bool gap_b = xi < 4 && !(PP_W4_DIAG & 2); // raw patch rows of the next quad
+                constexpr bool gap_c = (xi & 3) == 0;               // the VALU work of four steps
+                vcur = (xi & 3) == 0 ? o0[row & 1] : (xi & 3) == 3 ? o3[row & 1] : p12[row & 1][(xi & 3) - 1];
                 __builtin_amdgcn_sched_barrier(0);
-                W4_MFMA1(0, "")
+                W4_MFMA_1(0)
                 if constexpr (!(PP_W4_DIAG & 4)) {   // gap A: A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
                     constexpr int sa = s_ + AD - 1;
                     if constexpr (sa < NSTEP) {
@@ -1499,34 +1531,36 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                W4_MFMA1(1, "")
-                // gap B: next quad (the next CHUNK's first quad from ring slot nbuf when this is the chunk's last quad): one raw
-                // patch row per step over steps 0..3, column pass over steps 6..13
-                if constexpr (xi < 4 && !(PP_W4_DIAG & 2)) {
+                // gap B (steps 0..3 of a quad): one raw patch row of the next quad (the next CHUNK's first quad from ring slot nbuf
+                // when this is the chunk's last quad)
+                auto gap_b_body = [&]() {
                     if constexpr (xi == 0) {
                         qb = (c4 + 1 < NQ) ? buf * C::LDS_IN + rbase + (c4 + 1) * 4 * C::CS : nbuf * C::LDS_IN + rbase;
                         asm volatile("" : "+v"(qb));
                     }
-                    W4_READ_RAW_ROW(draw, qb, xi)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                W4_MFMA1(2, "")
-                // gap C of the EVEN steps carries the VALU work of two steps (every MFMA -> VALU -> MFMA turn costs a lone wave
-                // ~12 cycles on top of 4 per instruction, tools/issue_probe.hip), all of it packed: the B operands of steps s_+2 and
-                // s_+3 (row pass: 3 instructions per 4 steps), the normalisation of staging pieces s_ and s_+1, two column-pass terms of the next quad
-                if constexpr ((s_ & 1) == 0) {
-                    constexpr int sn = s_ + 2, c4n = sn / 16, xin = sn % 16;
-                    if constexpr ((xin & 3) == 0) { W4_ROW_FIRST(tq[c4n & 1], xin / 4) } else { W4_ROW_LAST(tq[c4n & 1], xin / 4) }
-                    if constexpr (!(PP_W4_DIAG & 16)) { W4_NORM_PAIR(s_, sc_, sh_, q_mask) }
-                    if constexpr (xi >= 6 && xi < 14) {
-                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 6)
-                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 6 + 1)
+                    if constexpr (xi < 4) { W4_READ_RAW_ROW(draw, qb, xi) }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // gap C (first step of every patch row) carries the VALU work of FOUR steps -- every MFMA -> VALU -> MFMA turn costs
+                // a lone wave ~12 cycles on top of 4 per instruction (tools/issue_probe.hip) -- all of it packed: the B operands of the
+                // next patch row's four steps (3 instructions), the normalisation of staging pieces s_ .. s_+3 (2 v_pk_fma_f32 +
+                // 4 v_med3_f32), and in rows 1 and 2 four column-pass terms of the next quad
+                auto gap_c_body = [&]() {
+                    constexpr int rn = row + 1; // next patch row; & 3 inside its quad, whose column pass sits in tq[(rn / 4) & 1]
+                    W4_ROW_ALL(tq[(rn / 4) & 1], rn)
+                    if constexpr (!(PP_W4_DIAG & 16)) { W4_NORM_PAIR(s_, sc_, sh_, q_mask) W4_NORM_PAIR(s_ + 2, sc_, sh_, q_mask) }
+                    if constexpr (xi == 4 || xi == 8) {
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 4)
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 4 + 1)
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 4 + 2)
+                        W4_COLPASS2(tq[(c4 + 1) & 1], draw, xi - 4 + 3)
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // The chunk's LAST MFMA carries the 12 wait states an 8-pass MFMA's D needs before anything but the next
-                // accumulating MFMA touches it (the epilogue's v_accvgpr_read after the last chunk; hipcc pads nothing behind an asm).
-                if constexpr (s_ + 1 < NSTEP) { W4_MFMA1(3, "") } else { W4_MFMA1(3, "\n\ts_nop 11") }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if constexpr (gap_b && gap_c) { W4_MFMA_1(1) gap_b_body(); W4_MFMA_1(2) gap_c_body(); W4_MFMA_1(3) }
+                else if constexpr (gap_b) { W4_MFMA_1(1) gap_b_body(); W4_MFMA_2(2) }
+                else if constexpr (gap_c) { W4_MFMA_2(1) gap_c_body(); W4_MFMA_1(3) }
+                else { W4_MFMA_3(1) }
                 // gap D: staging of chunk g+2 into ring slot wbuf, and the request that refills the register with chunk g+3's piece
                 if constexpr (s_ < NPIECE) {
                     if constexpr (!(PP_W4_DIAG & 16)) { W4_WRITE_PIECE(s_, ibw, wbw) }
@@ -1534,7 +1568,10 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-#undef W4_MFMA1
+#undef W4_MFMA_1
+#undef W4_MFMA_2
+#undef W4_MFMA_3
+#undef W4_ACC
             WN_STAMP(st2_)
             __syncthreads();
 #if PP_WINO_STAMP
@@ -1566,6 +1603,9 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
         WN_STAMP(se0_)
 #endif
         if (!(p.dbg & 4)) {
+        // an 8-pass MFMA's D needs 12 wait states before anything but the next accumulating MFMA touches it (hipcc pads nothing
+        // behind an asm statement)
+        asm volatile("s_nop 11" ::: W4_AGPRS);
         float* __restrict__ gout = p.out + fz * p.out_fs;
         const unsigned frame_bytes = (unsigned)((size_t)p.Cout * out_plane * 4);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(gout, 0, frame_bytes, 0x00020000);
@@ -1714,8 +1754,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #undef W4_READ_RAW_ROW
 #undef W4_WRITE_PIECE
 #undef W4_COLPASS2
-#undef W4_ROW_FIRST
-#undef W4_ROW_LAST
+#undef W4_ROW_ALL
 }
 
 // ------------------------------------------------------------------------------------------
