@@ -1140,7 +1140,7 @@ __device__ __forceinline__ f32x4 w4_pair_rows(float y0, float y1, float y2, floa
 #define PP_W4_STORE_AUX 0 // cache-policy bits of the epilogue's output stores (experiment: 2 = nt)
 #endif
 #ifndef PP_W4_RES_EARLY
-#define PP_W4_RES_EARLY 0 // 1: the first half's residual rows are requested at the top of the tile's last chunk (tried: the 32 registers they hold across the chunk spill)
+#define PP_W4_RES_EARLY 0 // 1: the first M-tile's residual rows are requested at the top of the tile's last chunk (tried: the 16 registers held across that chunk cost spills in the epilogue, 888 vs 890 frames/s; 32 registers -- the whole first half -- spilled in the chunk loop, 750)
 #endif
 #ifndef PP_W4_DIAG
 #define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
@@ -1433,14 +1433,12 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             const float* gres = p.res ? p.res + fz * p.res_fs : p.out;
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gres), 0, p.res ? (unsigned)((size_t)p.Cout * out_plane * 4) : 0u, 0x00020000);
         };
-        auto request_res = [&](auto HALF) { // 8 dwordx4 requests
-            constexpr int h = decltype(HALF)::value;
+        auto request_res = [&](auto HALF, auto II) { // the 4 residual rows of M-tile 2h+ii: dwordx4 requests
+            constexpr int h = decltype(HALF)::value, ii = decltype(II)::value;
             const __amdgpu_buffer_rsrc_t rres_ = res_desc();
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    rq[h][ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, lb0, (unsigned)((h * 2 + ii) * 16 + r) * plane_ob, 0));
+            for (int r = 0; r < 4; ++r)
+                rq[h][ii][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres_, lb0, (unsigned)((h * 2 + ii) * 16 + r) * plane_ob, 0));
         };
 
         // accumulator quad of (M-tile i, Winograd position xi): a[(xi*4 + i)*4 .. +3].  The tile's first 16 steps take 0 as C:
@@ -1467,7 +1465,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
             // the tile's last chunk: the first half's residual rows are requested a whole chunk before the epilogue adds them
             // (from HBM under load they took 3-6 k cycles, which the epilogue had to wait out: stamps)
-            if constexpr (PP_W4_RES_EARLY) { if (ch == nchunk - 1 && x4_map) request_res(std::integral_constant<int, 0>{}); }
+            if constexpr (PP_W4_RES_EARLY) { if (ch == nchunk - 1 && x4_map) request_res(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
             WN_STAMP(st1_)
             // One wave per SIMD issues IN ORDER: whatever follows an MFMA waits for that MFMA to enter the matrix pipe, and four
             // MFMAs in a row leave the other instructions only the last one's 32 cycles (measured: the 32 steps took the SUM of
@@ -1647,8 +1645,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             sum_p1_ += sh1_ - sh0_;
 #endif
         };
-        auto finish_half = [&](auto HALF, auto X4) {
-            constexpr int h = decltype(HALF)::value;
+        auto finish_mt = [&](auto HALF, auto II0, auto II1, auto X4) { // M-tiles 2h+II0 .. 2h+II1-1
+            constexpr int h = decltype(HALF)::value, ii0 = decltype(II0)::value, ii1 = decltype(II1)::value;
             constexpr bool x4 = decltype(X4)::value;
             WN_STAMP(sh0_)
             f32x2 r0[2][4], r1[2][4];
@@ -1664,7 +1662,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                     }
             }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
+            for (int ii = ii0; ii < ii1; ++ii) {
                 float ssum[4], ssq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1705,19 +1703,28 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             sum_p2_ += sh1_ - sh0_;
 #endif
         };
-        if (x4_map) {
-            if constexpr (!PP_W4_RES_EARLY) request_res(std::integral_constant<int, 0>{});
-            transform_half(std::integral_constant<int, 0>{});
-            if constexpr (PP_W4_RES_EARLY) request_res(std::integral_constant<int, 1>{});
-            finish_half(std::integral_constant<int, 0>{}, std::true_type{});
-            if constexpr (!PP_W4_RES_EARLY) request_res(std::integral_constant<int, 1>{});
-            transform_half(std::integral_constant<int, 1>{});
-            finish_half(std::integral_constant<int, 1>{}, std::true_type{});
-        } else {
-            transform_half(std::integral_constant<int, 0>{});
-            finish_half(std::integral_constant<int, 0>{}, std::false_type{});
-            transform_half(std::integral_constant<int, 1>{});
-            finish_half(std::integral_constant<int, 1>{}, std::false_type{});
+        {
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            if (x4_map) {
+                // every residual request is >= one transform + one M-tile's finish (~3.5 k cycles) ahead of its add; 32 registers
+                // rotate through the four M-tiles' rows (PP_W4_RES_EARLY: M-tile 0's were requested at the top of the last chunk)
+                if constexpr (!PP_W4_RES_EARLY) request_res(I0{}, I0{});
+                request_res(I0{}, I1{});
+                transform_half(I0{});
+                finish_mt(I0{}, I0{}, I1{}, std::true_type{});
+                request_res(I1{}, I0{});
+                finish_mt(I0{}, I1{}, I2{}, std::true_type{});
+                request_res(I1{}, I1{});
+                transform_half(I1{});
+                finish_mt(I1{}, I0{}, I2{}, std::true_type{});
+            } else {
+                transform_half(I0{});
+                finish_mt(I0{}, I0{}, I2{}, std::false_type{});
+                transform_half(I1{});
+                finish_mt(I1{}, I0{}, I2{}, std::false_type{});
+            }
         }
         if (p.stat_acc) {
             pending = true;

@@ -22,11 +22,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf -- pyth
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $O/pmcw.json 2> $O/pmcw.err
 unset PP_FORCE_VARIANT
 cd $R
-python tools/rocprof_stats.py $O/prof $((44 * 32)) 30 > $O/kernel_summary.txt
+# the profiled command runs (4 warm-up + 40 timed) passes of 32 frames twice: clouds resident, then from pinned host memory
+python tools/rocprof_stats.py $O/prof $((88 * 32)) 30 > $O/kernel_summary.txt
 python tools/pmc_summary.py $O/pmcs wino > $O/pmc_sq_waits.txt
 python tools/pmc_summary.py $O/pmci wino > $O/pmc_inst_mix.txt
 python tools/pmc_summary.py $O/pmcg wino > $O/pmc_clock.txt
 python tools/hbm_traffic.py $O/hbm_traffic.json 32 $((32 * 2 * 64 * 400 * 400 * 4)) "$T=$O/pmcf,$O/pmcw"
+# bench.py reports the PMC traffic figure only for the source tree it was taken on: publish it before the final line
+cp $O/hbm_traffic.json $R/profiles/r02_hbm_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 cp $(ls -t $O/prof/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 cat $O/kernel_summary.txt | head -40; cat $O/bench_default.json
