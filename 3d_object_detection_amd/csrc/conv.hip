@@ -1139,6 +1139,9 @@ __device__ __forceinline__ f32x4 w4_pair_rows(float y0, float y1, float y2, floa
 #ifndef PP_W4_STORE_AUX
 #define PP_W4_STORE_AUX 0 // cache-policy bits of the epilogue's output stores (experiment: 2 = nt)
 #endif
+#ifndef PP_W4_ONEGAP
+#define PP_W4_ONEGAP 0 // 1: all LDS / VMEM instructions of a step in ONE gap behind its last MFMA (tried: 872 against 890 frames/s); 0: A fragment behind the first MFMA, raw patch row behind the second, staging behind the last
+#endif
 #ifndef PP_W4_RES_EARLY
 #define PP_W4_RES_EARLY 0 // 1: the first M-tile's residual rows are requested at the top of the tile's last chunk (tried: the 16 registers held across that chunk cost spills in the epilogue, 888 vs 890 frames/s; 32 registers -- the whole first half -- spilled in the chunk loop, 750)
 #endif
@@ -1507,6 +1510,20 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                              :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(a[s_ % AD][(I) + 2]), "v"(vcur), W4_ACC(I), W4_ACC((I) + 1), W4_ACC((I) + 2) : W4_AGPRS); \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);
+#define W4_MFMA_4(I)                                                                             \
+            if constexpr (PP_W4_DIAG & 8) { asm volatile("" ::"v"(a[s_ % AD][I]), "v"(vcur)); }   \
+            else if constexpr (first_ && s_ < 16) {                                              \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c5:%c6], %0, %4, 0\n\tv_mfma_f32_16x16x4_f32 a[%c7:%c8], %1, %4, 0\n\t"            \
+                             "v_mfma_f32_16x16x4_f32 a[%c9:%c10], %2, %4, 0\n\tv_mfma_f32_16x16x4_f32 a[%c11:%c12], %3, %4, 0"             \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(a[s_ % AD][(I) + 2]), "v"(a[s_ % AD][(I) + 3]), "v"(vcur), \
+                                W4_ACC(I), W4_ACC((I) + 1), W4_ACC((I) + 2), W4_ACC((I) + 3) : W4_AGPRS);                                    \
+            } else {                                                                             \
+                asm volatile("v_mfma_f32_16x16x4_f32 a[%c5:%c6], %0, %4, a[%c5:%c6]\n\tv_mfma_f32_16x16x4_f32 a[%c7:%c8], %1, %4, a[%c7:%c8]\n\t" \
+                             "v_mfma_f32_16x16x4_f32 a[%c9:%c10], %2, %4, a[%c9:%c10]\n\tv_mfma_f32_16x16x4_f32 a[%c11:%c12], %3, %4, a[%c11:%c12]" \
+                             :: "v"(a[s_ % AD][I]), "v"(a[s_ % AD][(I) + 1]), "v"(a[s_ % AD][(I) + 2]), "v"(a[s_ % AD][(I) + 3]), "v"(vcur), \
+                                W4_ACC(I), W4_ACC((I) + 1), W4_ACC((I) + 2), W4_ACC((I) + 3) : W4_AGPRS);                                    \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);
 #ifdef PP_W4_ALIGN
             asm volatile(".p2align " PP_W4_ALIGN);
 #endif
@@ -1517,8 +1534,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                 constexpr bool gap_c = (xi & 3) == 0;               // the VALU work of four steps
                 vcur = (xi & 3) == 0 ? o0[row & 1] : (xi & 3) == 3 ? o3[row & 1] : p12[row & 1][(xi & 3) - 1];
                 __builtin_amdgcn_sched_barrier(0);
-                W4_MFMA_1(0)
-                if constexpr (!(PP_W4_DIAG & 4)) {   // gap A: A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
+                auto gap_a_body = [&]() {   // the A fragment of step s_+AD-1 (this chunk, or the next chunk's first steps from ring slot nbuf)
+                  if constexpr (!(PP_W4_DIAG & 4)) {
                     constexpr int sa = s_ + AD - 1;
                     if constexpr (sa < NSTEP) {
                         constexpr int n4_ = sa / 16, nx_ = sa % 16;
@@ -1527,8 +1544,8 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                         constexpr int sb = sa - NSTEP, n4_ = sb / 16, nx_ = sb % 16;
                         a[sa % AD] = *reinterpret_cast<const f32x4*>(wbn + (nx_ * KC + n4_ * 4) * C::BM + aoff);
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                  }
+                };
                 // gap B (steps 0..3 of a quad): one raw patch row of the next quad (the next CHUNK's first quad from ring slot nbuf
                 // when this is the chunk's last quad)
                 auto gap_b_body = [&]() {
@@ -1537,7 +1554,6 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                         asm volatile("" : "+v"(qb));
                     }
                     if constexpr (xi < 4) { W4_READ_RAW_ROW(draw, qb, xi) }
-                    __builtin_amdgcn_sched_barrier(0);
                 };
                 // gap C (first step of every patch row) carries the VALU work of FOUR steps -- every MFMA -> VALU -> MFMA turn costs
                 // a lone wave ~12 cycles on top of 4 per instruction (tools/issue_probe.hip) -- all of it packed: the B operands of the
@@ -1555,10 +1571,21 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                if constexpr (gap_b && gap_c) { W4_MFMA_1(1) gap_b_body(); W4_MFMA_1(2) gap_c_body(); W4_MFMA_1(3) }
-                else if constexpr (gap_b) { W4_MFMA_1(1) gap_b_body(); W4_MFMA_2(2) }
-                else if constexpr (gap_c) { W4_MFMA_2(1) gap_c_body(); W4_MFMA_1(3) }
-                else { W4_MFMA_3(1) }
+                if constexpr (PP_W4_ONEGAP) {
+                    // ONE memory gap per step, behind its last MFMA: the first LDS / VMEM instruction after an MFMA costs a lone wave
+                    // ~6 cycles, further ones 0.5 (tools/issue_probe.hip); the four MFMAs come from one asm statement
+                    if constexpr (gap_c) { W4_MFMA_3(0) gap_c_body(); W4_MFMA_1(3) } else { W4_MFMA_4(0) }
+                    gap_a_body();
+                    if constexpr (gap_b) gap_b_body();
+                } else {
+                    W4_MFMA_1(0)
+                    gap_a_body();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (gap_b && gap_c) { W4_MFMA_1(1) gap_b_body(); __builtin_amdgcn_sched_barrier(0); W4_MFMA_1(2) gap_c_body(); W4_MFMA_1(3) }
+                    else if constexpr (gap_b) { W4_MFMA_1(1) gap_b_body(); __builtin_amdgcn_sched_barrier(0); W4_MFMA_2(2) }
+                    else if constexpr (gap_c) { W4_MFMA_2(1) gap_c_body(); W4_MFMA_1(3) }
+                    else { W4_MFMA_3(1) }
+                }
                 // gap D: staging of chunk g+2 into ring slot wbuf, and the request that refills the register with chunk g+3's piece
                 if constexpr (s_ < NPIECE) {
                     if constexpr (!(PP_W4_DIAG & 16)) { W4_WRITE_PIECE(s_, ibw, wbw) }
@@ -1569,6 +1596,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #undef W4_MFMA_1
 #undef W4_MFMA_2
 #undef W4_MFMA_3
+#undef W4_MFMA_4
 #undef W4_ACC
             WN_STAMP(st2_)
             __syncthreads();
