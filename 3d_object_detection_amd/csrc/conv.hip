@@ -2506,6 +2506,13 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         if (++it == 8) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
     }
+    if (blockIdx.x == 0 && (int)threadIdx.x < (HW & 3)) { // planes whose pixel count is no multiple of 4 (odd level-2 maps, e.g. 9 x 11)
+        const size_t e = (size_t)c * HW + ((size_t)n4 << 2) + threadIdx.x;
+        const float v = fmaxf(fmaf(x[e], sc, sh), 0.f);
+        y[e] = v;
+        s += v;
+        q += v * v;
+    }
     ds += s;
     dq += q;
     if (!stat_acc) return;
@@ -2747,6 +2754,9 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
 }
 
 bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
+// shape limits of a tiling family: wino4_mfma stores float2 rows (even output width); gemm1x1 feeds four N-tiles from one
+// dwordx4 of 4 consecutive pixels of the input plane (pixel count a multiple of 4 -- a 9 x 11 map has 99)
+bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)); }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -2770,7 +2780,7 @@ Variant pick_variant(int kind, int stride, int up, int rows, int Hout, int Wout,
                                                     : nullptr;
     if (prefer)
         for (const Variant& v : menu)
-            if (variant_ok(v, rows) && !strcmp(v.name, prefer)) return v;
+            if (variant_ok(v, rows) && shape_ok(v, Hout, Wout, Wout) && !strcmp(v.name, prefer)) return v;
     return bv;
 }
 
@@ -3001,6 +3011,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
     dim3 grid(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph), pp_div_up(L.rows, v.bm), B);
     p.nb = B;
     size_t lds_bytes = v.lds;
+    if (v.wino == 3 && ((Hin * Win) & 3)) return PP_E_ARG; // gemm1x1 reads pixel quads (choose_variant never offers it for such a plane)
     if (v.wino == 3) lds_bytes = g1_lds(v, L.cin);
     if (v.wino == 2 || v.wino == 3) { // persistent: one workgroup per CU, a multiple of the row-block count
         const int ncb = pp_div_up(L.rows, v.bm);
@@ -3049,8 +3060,9 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         const double tile_us = 2.4 * (L.cin / 8) + 5.0;
         const double full = rounds(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph)) * tile_us;
         const double split = (rounds(t_main) + rounds(t_right) + rounds(t_bottom)) * tile_us + 30.0 * ((t_right > 0) + (t_bottom > 0));
-        static const bool no_strips = getenv("PP_W4_STRIPS") && getenv("PP_W4_STRIPS")[0] == '0';
-        if (split < full && mw > 0 && mh > 0 && !no_strips) {
+        const char* strips_env = getenv("PP_W4_STRIPS"); // read per launch (tests switch it); 0: never, 2: whenever whole main tiles exist (parity tests of the strip tiles on small maps)
+        const bool no_strips = strips_env && strips_env[0] == '0', all_strips = strips_env && strips_env[0] == '2';
+        if ((split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
             launch_region(v, 0, 0, mw, mh);
             if (Wout > mw) launch_region(sv, mw, 0, Wout, Hout);
             if (Hout > mh) launch_region(sh, 0, mh, mw, Hout);
@@ -3176,7 +3188,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     const int rows = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
-            if (variant_ok(v, rows) && !(v.wino == 4 && (Wout & 1)) && strstr(v.name, force)) { L.var = v; return 0; }
+            if (variant_ok(v, rows) && shape_ok(v, Hin, Win, Wout) && strstr(v.name, force)) { L.var = v; return 0; }
     }
     auto hit = tune_cache().find(sig);
     if (hit != tune_cache().end()) {
@@ -3215,7 +3227,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     std::vector<std::pair<double, const Variant*>> timed;
     for (const Variant& v : menu) {
         if (!variant_ok(v, rows)) continue;
-        if (v.wino == 4 && (Wout & 1)) continue; // float2 row stores
+        if (!shape_ok(v, Hin, Win, Wout)) continue;
         const size_t need = (v.wino == 3) ? g1_lds(v, L.cin) : v.lds;
         if (need > 160 * 1024) continue;
         double ms;

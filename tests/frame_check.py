@@ -28,9 +28,10 @@ TOL = 1e-3          # north-star tolerance on box fields and scores
 SCORE_THR, IOU_THR, PRE_MAX, POST_MAX = 0.05, 0.1, 1000, 300
 
 
-def oracle_frame(synth, name, pts, sd, norm="instance", num_anchor_per_loc=9, setup=None, anchors=None):
-    """voxelise -> mask -> PFN -> scatter -> backbone -> head on the CPU oracle (logits, not detections)."""
+def oracle_frame(synth, name, pts, sd, norm="instance", num_anchor_per_loc=9, setup=None, anchors=None, over=None):
+    """voxelise -> mask -> PFN -> scatter -> backbone -> head on the CPU oracle (logits, not detections).  over: config keys to replace."""
     cfg = synth.load_config(name)
+    cfg.update(over or {})
     s = setup or O.voxel_setup(cfg)
     a = anchors or O.make_anchors(s, class_table=cfg.get("class_table"))
     if cfg.get("class_table"):

@@ -154,6 +154,24 @@ def test_fused_frame_vs_oracle(name, norm, nms_mode, bias, synth):
     compare_frame(r, gpu_logits(eng, 0), det[:cnt[0]].cpu().numpy(), cnt, nms_mode, f"fused {name} {norm} nms{nms_mode}")
 
 
+def test_fused_frame_odd_level2_maps(synth):
+    """A grid whose eighth is odd: 72 x 88 cells -> 36 x 44, 18 x 22 and 9 x 11 maps (99 pixels, odd width) through every kernel of
+    the path.  (Round 2 found, with the backbone-level twin of this test, a dropped tail in norm_relu_stats for planes whose pixel
+    count is no multiple of 4 and the same assumption in gemm1x1, which is no longer offered for such planes.)"""
+    eng_mod = load_pkg("engine")
+    over = dict(detection_range=[0.0, -8.8, -2.5, 14.4, 8.8, 8.5], max_voxels=4000)
+    sd = synth.seeded_state_dict(6, cls_bias=-3.0)
+    eng = eng_mod.Engine(make_cfg(synth, "eight_20cm", **over))
+    eng.load_state_dict(sd)
+    assert (eng.H, eng.W) == (36, 44)
+    pts = synth.lidar_cloud("eight_20cm", seed=5)
+    det, cnt = eng.infer_frame(torch.from_numpy(pts).cuda())
+    cnt = cnt.cpu().numpy()
+    r = oracle_frame(synth, "eight_20cm", pts, sd, over=over)
+    assert r["coors"].shape[0] > 300
+    compare_frame(r, gpu_logits(eng, 0), det[:cnt[0]].cpu().numpy(), cnt, 0, "fused eight_20cm 72x88 grid (odd level-2 maps)")
+
+
 def test_ntusl_10cm_whole_path(synth):
     """BASELINE config 3 (configs/ntusl_10cm.json: 0.1 m pillars, 1600x1600 BEV, 5.76 M anchors, 60 k-point cloud) through
     PFN / backbone / head / post-processing: frame 0 of a 2-frame pp_infer_batch against the CPU oracle, frame 1 against

@@ -245,6 +245,27 @@ def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
         np.testing.assert_allclose(p["dir_preds"].cpu().numpy(), dr, rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("force,strips", [("wino4 tw4 bx2", "2"), ("wino4 tw8 bx1", "2"), ("wino4 tw8 bx2", "2"), ("wino4 tw4 bx2", "0")])
+def test_backbone_wino4_edge_maps(force, strips, fw, synth, monkeypatch):
+    """wino4_mfma on maps that are no multiple of its tile: 72 x 88 canvas -> 36 x 44 (dwordx4 rows), 18 x 22 (width = 2 mod 4:
+    the dwordx2 form of the epilogue) and 9 x 11 (odd: another kernel takes over) maps, with the region launches forced
+    (PP_W4_STRIPS=2: whole main tiles + right / bottom strips of thin tiles, regions starting off a multiple of 4) and disabled,
+    against the CPU oracle's backbone."""
+    monkeypatch.setenv("PP_FORCE_VARIANT", force)
+    monkeypatch.setenv("PP_W4_STRIPS", strips)
+    cfg = small_cfg(synth, 72, 88)
+    fw["vg"].VoxelGenerator(cfg)
+    net = fw["shared"].PointPillars(cfg)
+    sd = synth.seeded_state_dict(4)
+    net.load_state_dict(sd)
+    x = np.random.default_rng(11).standard_normal((1, 64, 72, 88)).astype(np.float32)
+    x[:, :, ::3, ::2] = 0.0
+    y = net.rpn(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = O.backbone(x, sd)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-4)
+
+
 def test_head_layout(fw, synth):
     g = golden("head_small")
     cfg = small_cfg(synth, 16, 12)
