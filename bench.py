@@ -49,17 +49,17 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def hbm_traffic(tiling, frames):
+def hbm_traffic(tiling, frames, H, W):
     """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside this process, so the figure
     comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_round.sh +
     tools/hbm_traffic.py; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -- and only if they were
-    taken for the tiling, the batch AND the source tree that is running; otherwise null."""
+    taken for the layer shape, the tiling, the batch AND the source tree that is running; otherwise null."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             e = t["tilings"].get(tiling)
-            if e is None or t["frames_per_launch"] != frames or t.get("source_hash") != source_hash():
+            if e is None or t["frames_per_launch"] != frames or t.get("source_hash") != source_hash() or not t.get("layer", "").endswith(f"@ {H}x{W}"):
                 continue
             return int(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
         except (OSError, KeyError, ValueError):
@@ -362,7 +362,7 @@ def main():
                        "global_batch": args.global_batch or None, "cls_bias": args.cls_bias, "mean_detections": mean_det},
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0
-        traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), min(NB, MAXB))
+        traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), min(NB, MAXB), eng.H, eng.W)
         out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{min(NB, MAXB)} frames, tiling '{eng.dominant_kernel()}'",
                            "achieved": round(ach * ratio, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach * ratio / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
