@@ -1146,7 +1146,7 @@ __device__ __forceinline__ f32x4 w4_pair_rows(float y0, float y1, float y2, floa
 #define PP_W4_RES_EARLY 0 // 1: the first M-tile's residual rows are requested at the top of the tile's last chunk (tried: the 16 registers held across that chunk cost spills in the epilogue, 888 vs 890 frames/s; 32 registers -- the whole first half -- spilled in the chunk loop, 750)
 #endif
 #ifndef PP_W4_DIAG
-#define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads
+#define PP_W4_DIAG 0 // timing-only ablations of wino4_mfma's step loop (wrong results): 1 no transform VALU, 2 no raw LDS reads, 4 no A LDS reads, 8 no MFMA, 16 no LDS writes, 32 no s_nop pad, 64 no global loads, 128 load side frozen (no advance() at the chunk top), 256 no chunk barrier
 #endif
 template <int TWT, int BTX, int KC>
 struct Wino4Cfg {
@@ -1464,19 +1464,24 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
             float q_mask[C::PR]; // upper clamp of the normalised value: +inf inside the image, 0 on the zero padding (v_med3_f32 does ReLU and padding in one)
 #pragma unroll
             for (int r = 0; r < C::PR; ++r) q_mask[r] = ((r_vmask >> r) & 1u) ? __builtin_inff() : 0.f;
+            if constexpr (!(PP_W4_DIAG & 128)) {
             advance();
             r_tab = s_tab; r_c0 = s_ch * KC; r_vmask = vmask;
+            }
             // the tile's last chunk: the first half's residual rows are requested a whole chunk before the epilogue adds them
             // (from HBM under load they took 3-6 k cycles, which the epilogue had to wait out: stamps)
             if constexpr (PP_W4_RES_EARLY) { if (ch == nchunk - 1 && x4_map) request_res(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
             WN_STAMP(st1_)
-            // One wave per SIMD issues IN ORDER: whatever follows an MFMA waits for that MFMA to enter the matrix pipe, and four
-            // MFMAs in a row leave the other instructions only the last one's 32 cycles (measured: the 32 steps took the SUM of
-            // the MFMA-only and the MFMA-free loop, 4.2 k + 2.5 k cycles per chunk).  So each step is MFMA, gap, MFMA, gap, ...:
-            //   gap A: the A fragment of step s+3 (one ds_read_b128)      gap B: raw patch row of the next quad / its column pass
-            //   gap C: row pass of step s+1's B operand, normalise piece s  gap D: LDS write of piece s + the request that refills it
-            // (<= 24 issue cycles per gap hide under the 32-cycle MFMA).  A B operand is written two gaps before its first use and
-            // the A fragments come from LDS behind hipcc's own lgkmcnt wait, so the asm MFMAs need no s_nop pad.
+            // One wave per SIMD issues IN ORDER and nothing of its own hides behind an fp32 MFMA (tools/issue_probe.hip): a VALU
+            // instruction costs its 4 issue cycles wherever it stands and every MFMA -> VALU -> MFMA turn ~12 more; SALU 0.5 cycle;
+            // the first LDS / VMEM instruction of a gap ~6.  The step = 4 MFMAs of one Winograd position and channel quad:
+            //   MFMA 0 | gap A: the A fragment of step s+3 (one ds_read_b128)
+            //   MFMA 1 | gap B (steps 0..3 of a quad): one raw patch row of the next quad (two ds_read2_b32)
+            //   MFMA 2 | gap C (first step of a patch row only): ALL the VALU work of four steps, packed (see gap_c_body)
+            //   MFMA 3 | gap D (steps 0..23): LDS write of staging piece s + the request that refills its register
+            // MFMAs with an empty gap between them share one asm statement.  A B operand is written >= 1 step before its first
+            // use and the A fragments come from LDS behind hipcc's own lgkmcnt wait, so the asm MFMAs need no s_nop pad.
+            // (All memory instructions in ONE gap behind MFMA 3 -- PP_W4_ONEGAP -- measured slower, 872 against 890 frames/s.)
 // N MFMAs of one step (M-tiles I .. I+N-1) in ONE asm statement: hipcc pads every boundary between two asm statements
 // with an s_nop, so MFMAs with nothing to put between them are issued from one statement
 #define W4_ACC(I) "i"((xi * 4 + (I)) * 4), "i"((xi * 4 + (I)) * 4 + 3)
@@ -1599,7 +1604,7 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
 #undef W4_MFMA_4
 #undef W4_ACC
             WN_STAMP(st2_)
-            __syncthreads();
+            if constexpr (!(PP_W4_DIAG & 256)) __syncthreads();
 #if PP_WINO_STAMP
             WN_STAMP(st3_)
             sum_pre_ += st1_ - st0_; sum_steps_ += st2_ - st1_; sum_bar_ += st3_ - st2_; n_chunks_ += 1;
