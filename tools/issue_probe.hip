@@ -98,6 +98,38 @@ KERNEL(k_dsrd4x1, DSRD4)
 KERNEL(k_dswr1, DSWR)
 KERNEL(k_mix, VADD_A DSRD_B VADD_C SADD)
 
+
+// The step loop of wino4_mfma in miniature (per 16 MFMAs = one patch row: 4 A-fragment reads, one cluster of 10 VALU, 3 LDS writes)
+// against the same filler work per 8 MFMAs (an MT = 2 kernel: every B operand feeds 2 MFMAs instead of 4), to be run with two
+// waves per SIMD.  BODY16 / BODY8 are one iteration each.
+#define V10 VADD_A VADD_B VADD_C VADD_D PK_A PK_B VADD_A VADD_B PK_A PK_B
+#define BODY16 MF(0) DSRD4 MF(1) MF(2) V10 MF(3) DSWR MF(4) DSRD4 MF(5) MF(6) MF(7) DSWR MF(0) DSRD4 MF(1) MF(2) MF(3) DSWR MF(4) DSRD4 MF(5) MF(6) MF(7) "s_waitcnt lgkmcnt(0)\n"
+#define BODY8 MF(0) DSRD4 MF(1) V10 MF(2) DSWR MF(3) DSRD4 MF(4) DSWR MF(5) DSRD4 MF(6) DSWR MF(7) DSRD4 "s_waitcnt lgkmcnt(0)\n"
+#define KERNEL2(NAME, BODYX)                                                                                         \
+    __global__ void __launch_bounds__(512) NAME(unsigned long long* out, int iters, int mode)                         \
+    {                                                                                                                \
+        __shared__ float lds[4096];                                                                                  \
+        f32x4 acc[8];                                                                                                \
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};                                            \
+        float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f, f0 = a, f1 = b, f2 = a, f3 = b;                      \
+        f32x2 p0 = {a, b}, p1 = {b, a}, p2 = {a, a};                                                                 \
+        f32x4 q0 = {a, b, a, b};                                                                                     \
+        lds[threadIdx.x] = a;                                                                                        \
+        unsigned la = (threadIdx.x & 63) * 16;                                                                       \
+        __syncthreads();                                                                                             \
+        const int wave = threadIdx.x >> 6;                                                                           \
+        unsigned long long t0, t1;                                                                                   \
+        asm volatile("s_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t0));                                               \
+        for (int it = 0; it < iters; ++it) asm volatile(BODYX OPERANDS);                                             \
+        asm volatile("s_nop 15\ns_nop 15\ns_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t1));                           \
+        float s = f0 + f1 + f2 + f3 + p0[0] + p1[0] + p2[1] + q0[0];                                                 \
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];                                                      \
+        if (s == 12345.678f) out[100] = 1;                                                                           \
+        if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;                                                            \
+    }
+KERNEL2(k_step16, BODY16)
+KERNEL2(k_step8, BODY8)
+
 typedef void (*kfn)(unsigned long long*, int, int);
 struct Ent { const char* name; kfn f; int fillers; };
 
@@ -134,6 +166,24 @@ int main()
             if (cfg >= 2 && e.fillers) fill[cfg - 2] = (double)m47 / ((double)iters * 4 * 8 * e.fillers);
         }
         printf("%-28s %8.1f %8.1f %8.1f %8.1f | %6.1f %6.1f\n", e.name, r[0], r[1], r[1] / 2, r[2], fill[0], fill[1]);
+    }
+    {   // whole-step patterns
+        printf("step-loop patterns (cycles per MFMA per SIMD): wino4-like, 16 MFMAs + 10 VALU + 4 ds_read_b128 + 3 ds_write per iteration, and the same filler work per 8 MFMAs (MT = 2)\n");
+        struct P { const char* name; kfn f; int mf; } ps[] = {{"16 MFMAs per filler set", k_step16, 16}, {"8 MFMAs per filler set", k_step8, 8}};
+        for (const P& q : ps)
+            for (int threads = 256; threads <= 512; threads += 256) {
+                unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int rep = 0; rep < 2; ++rep) {
+                    CK(hipMemset(out, 0, 64));
+                    hipLaunchKernelGGL(q.f, dim3(1), dim3(threads), 0, 0, out, iters, 0);
+                    CK(hipDeviceSynchronize());
+                }
+                CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+                unsigned long long m = 0;
+                for (int w = 0; w < 8; ++w) if (h[w] > m) m = h[w];
+                const int waves = threads / 256;
+                printf("%-28s %d wave(s) per SIMD: %6.1f cycles per MFMA per SIMD\n", q.name, waves, (double)m / ((double)iters * q.mf * waves));
+            }
     }
     return 0;
 }
