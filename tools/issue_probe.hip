@@ -130,6 +130,44 @@ KERNEL(k_mix, VADD_A DSRD_B VADD_C SADD)
 KERNEL2(k_step16, BODY16)
 KERNEL2(k_step8, BODY8)
 
+// Same mix with the A fragments really flowing through LDS: each group of 4 MFMAs takes its A operands from the ds_read_b128 issued
+// three groups earlier (registers v[200:215], rotating) behind the s_waitcnt hipcc would put there -- the dependence the product
+// kernel has and the patterns above lack.
+#define MFA(i, r) "v_mfma_f32_16x16x4_f32 %" #i ", v" #r ", %17, %" #i "\n"
+#define GRP(w, r0, r1, r2, r3, ld, MID) "s_waitcnt lgkmcnt(" #w ")\n" MFA(0, r0) "ds_read_b128 v[" #ld "], %18 offset:1024\n" MFA(1, r1) MID MFA(2, r2) MFA(3, r3)
+#define BODY16D GRP(2, 200, 201, 202, 203, 212:215, "") GRP(2, 204, 205, 206, 207, 200:203, V10) GRP(2, 208, 209, 210, 211, 204:207, "") GRP(2, 212, 213, 214, 215, 208:211, "")
+#define KERNEL3(NAME, BODYX)                                                                                         \
+    __global__ void __launch_bounds__(512) NAME(unsigned long long* out, int iters, int mode)                         \
+    {                                                                                                                \
+        __shared__ float lds[4096];                                                                                  \
+        f32x4 acc[8];                                                                                                \
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};                                            \
+        float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f, f0 = a, f1 = b, f2 = a, f3 = b;                      \
+        f32x2 p0 = {a, b}, p1 = {b, a}, p2 = {a, a};                                                                 \
+        f32x4 q0 = {a, b, a, b};                                                                                     \
+        lds[threadIdx.x] = a;                                                                                        \
+        unsigned la = (threadIdx.x & 63) * 16;                                                                       \
+        __syncthreads();                                                                                             \
+        const int wave = threadIdx.x >> 6;                                                                           \
+        unsigned long long t0, t1;                                                                                   \
+        asm volatile("ds_read_b128 v[200:203], %0\nds_read_b128 v[204:207], %0\nds_read_b128 v[208:211], %0\nds_read_b128 v[212:215], %0\ns_waitcnt lgkmcnt(0)\n" \
+                     "ds_read_b128 v[200:203], %0\nds_read_b128 v[204:207], %0\nds_read_b128 v[208:211], %0" :: "v"(la) : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"); \
+        asm volatile("s_memtime %0" : "=s"(t0));                                                                      \
+        for (int it = 0; it < iters; ++it)                                                                           \
+            asm volatile(BODYX OPERANDS_D);                                                                          \
+        asm volatile("s_nop 15\ns_nop 15\ns_memtime %0\ns_waitcnt lgkmcnt(0)" : "=s"(t1));                           \
+        float s = f0 + f1 + f2 + f3 + p0[0] + p1[0] + p2[1] + q0[0];                                                 \
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];                                                      \
+        if (s == 12345.678f) out[100] = 1;                                                                           \
+        if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;                                                            \
+    }
+#define OPERANDS_D                                                                                                   \
+    : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), \
+      "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0)                                  \
+    : "v"(a), "v"(b), "v"(la)                                                                                        \
+    : "s40", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
+KERNEL3(k_step16d, BODY16D)
+
 typedef void (*kfn)(unsigned long long*, int, int);
 struct Ent { const char* name; kfn f; int fillers; };
 
@@ -169,7 +207,8 @@ int main()
     }
     {   // whole-step patterns
         printf("step-loop patterns (cycles per MFMA per SIMD): wino4-like, 16 MFMAs + 10 VALU + 4 ds_read_b128 + 3 ds_write per iteration, and the same filler work per 8 MFMAs (MT = 2)\n");
-        struct P { const char* name; kfn f; int mf; } ps[] = {{"16 MFMAs per filler set", k_step16, 16}, {"8 MFMAs per filler set", k_step8, 8}};
+        struct P { const char* name; kfn f; int mf; } ps[] = {{"16 MFMAs per filler set", k_step16, 16}, {"8 MFMAs per filler set", k_step8, 8},
+                                                              {"16 MFMAs, A through LDS", k_step16d, 16}};
         for (const P& q : ps)
             for (int threads = 256; threads <= 512; threads += 256) {
                 unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
