@@ -68,3 +68,25 @@ def test_tuning_is_shared_not_repeated():
     e1 = stub.Engine({})
     e1.load_state_dict({})
     assert e0.tuned_here and not e1.tuned_here and "imported" in e1.dominant_kernel()
+
+
+def test_pmc_traffic_only_for_the_profiled_build_and_shape():
+    """roofline.traffic comes from a committed rocprofv3 --pmc pass: bench.py may quote it only for the layer shape, tiling,
+    batch and HIP source tree it was taken on (sha256 of csrc/*.hip + *.h), otherwise null."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json"))
+    assert files
+    t = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    tiling = next(iter(t["tilings"]))
+    h, w = (int(v) for v in t["layer"].split("@")[1].split("x"))
+    got, src = bench.hbm_traffic(tiling, t["frames_per_launch"], h, w)
+    if t.get("source_hash") == bench.source_hash():   # the committed figure belongs to this very tree
+        assert got == int(t["tilings"][tiling]["hbm_bytes_per_launch"]) and files[-1] in src
+    else:
+        assert got is None
+    assert bench.hbm_traffic(tiling, t["frames_per_launch"], h // 2, w)[0] is None          # another layer shape
+    assert bench.hbm_traffic(tiling, t["frames_per_launch"] + 1, h, w)[0] is None           # another batch
+    assert bench.hbm_traffic("no such tiling", t["frames_per_launch"], h, w)[0] is None
