@@ -147,6 +147,7 @@ KERNEL2(k_step8, BODY8)
         f32x4 q0 = {a, b, a, b};                                                                                     \
         lds[threadIdx.x] = a;                                                                                        \
         unsigned la = (threadIdx.x & 63) * 16;                                                                       \
+        const unsigned long long* gp = out + 16 + (threadIdx.x & 63) * 2;                                            \
         __syncthreads();                                                                                             \
         const int wave = threadIdx.x >> 6;                                                                           \
         unsigned long long t0, t1;                                                                                   \
@@ -164,9 +165,30 @@ KERNEL2(k_step8, BODY8)
 #define OPERANDS_D                                                                                                   \
     : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), \
       "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0)                                  \
-    : "v"(a), "v"(b), "v"(la)                                                                                        \
-    : "s40", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
+    : "v"(a), "v"(b), "v"(la), "v"(gp)                                                                               \
+    : "s40", "memory", "v199", "v198", "v197", "v196", "v195", "v194", "v193", "v192", "v191", "v190", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
 KERNEL3(k_step16d, BODY16D)
+// the product kernel's whole memory mix per 16 MFMAs: + 2 ds_read2_b32 (raw patch row), 2 ds_write_b32 + 1 ds_write_b128 (staging),
+// 2 global_load_dword + 1 global_load_dwordx4 (refills), each behind its MFMA like the product's gaps
+#define RAW2 "ds_read2_b32 v[198:199], %18 offset0:1 offset1:9\nds_read2_b32 v[196:197], %18 offset0:2 offset1:10\n"
+#define STG "ds_write_b32 %18, %10 offset:8192\nglobal_load_dword v195, %19, off\n"
+#define STG4 "ds_write_b128 %18, %15 offset:12288\nglobal_load_dwordx4 v[190:193], %19, off\n"
+#define GRPR(w, r0, r1, r2, r3, ld, B_, C_, D_) "s_waitcnt lgkmcnt(" #w ")\n" MFA(0, r0) "ds_read_b128 v[" #ld "], %18 offset:1024\n" MFA(1, r1) B_ MFA(2, r2) C_ MFA(3, r3) D_
+#define BODY16R GRPR(6, 200, 201, 202, 203, 212:215, RAW2, V10, STG) GRPR(6, 204, 205, 206, 207, 200:203, "", "", STG) GRPR(6, 208, 209, 210, 211, 204:207, "", "", STG4) GRPR(6, 212, 213, 214, 215, 208:211, "", "", "s_waitcnt vmcnt(3)\n")
+KERNEL3(k_step16r, BODY16R)
+#define STG_NG "ds_write_b32 %18, %10 offset:8192\n"
+#define STG4_NG "ds_write_b128 %18, %15 offset:12288\n"
+#define BODY16R_NOGL GRPR(6, 200, 201, 202, 203, 212:215, RAW2, V10, STG_NG) GRPR(6, 204, 205, 206, 207, 200:203, "", "", STG_NG) GRPR(6, 208, 209, 210, 211, 204:207, "", "", STG4_NG) GRPR(6, 212, 213, 214, 215, 208:211, "", "", "")
+#define BODY16R_NOW4 GRPR(6, 200, 201, 202, 203, 212:215, RAW2, V10, STG) GRPR(6, 204, 205, 206, 207, 200:203, "", "", STG) GRPR(6, 208, 209, 210, 211, 204:207, "", "", STG) GRPR(6, 212, 213, 214, 215, 208:211, "", "", "s_waitcnt vmcnt(3)\n")
+#define BODY16R_NORAW GRPR(6, 200, 201, 202, 203, 212:215, "", V10, STG) GRPR(6, 204, 205, 206, 207, 200:203, "", "", STG) GRPR(6, 208, 209, 210, 211, 204:207, "", "", STG4) GRPR(6, 212, 213, 214, 215, 208:211, "", "", "s_waitcnt vmcnt(3)\n")
+#define BODY16R_NOSTG GRPR(6, 200, 201, 202, 203, 212:215, RAW2, V10, "") GRPR(6, 204, 205, 206, 207, 200:203, "", "", "") GRPR(6, 208, 209, 210, 211, 204:207, "", "", "") GRPR(6, 212, 213, 214, 215, 208:211, "", "", "")
+KERNEL3(k_r_nogl, BODY16R_NOGL)
+KERNEL3(k_r_now4, BODY16R_NOW4)
+KERNEL3(k_r_noraw, BODY16R_NORAW)
+KERNEL3(k_r_nostg, BODY16R_NOSTG)
+// the same, 8 x unrolled (128 MFMAs of straight-line code per iteration, like one chunk body of the product kernel): instruction fetch
+#define BODY128D BODY16D BODY16D BODY16D BODY16D BODY16D BODY16D BODY16D BODY16D
+KERNEL3(k_step128d, BODY128D)
 
 typedef void (*kfn)(unsigned long long*, int, int);
 struct Ent { const char* name; kfn f; int fillers; };
@@ -174,7 +196,7 @@ struct Ent { const char* name; kfn f; int fillers; };
 int main()
 {
     unsigned long long* out;
-    CK(hipMalloc(&out, 1024));
+    CK(hipMalloc(&out, 8192));
     const int iters = 4000;
     Ent ents[] = {{"none", k_none, 0}, {"v_add x1", k_vadd1, 1}, {"v_add x2", k_vadd2, 2}, {"v_add x4", k_vadd4, 4}, {"v_add x6", k_vadd6, 6},
                   {"v_add own regs x1", k_vown1, 1}, {"v_add own regs x2", k_vown2, 2}, {"v_add own regs x4", k_vown4, 4}, {"v_add dependent x4", k_vdep4, 4},
@@ -208,7 +230,8 @@ int main()
     {   // whole-step patterns
         printf("step-loop patterns (cycles per MFMA per SIMD): wino4-like, 16 MFMAs + 10 VALU + 4 ds_read_b128 + 3 ds_write per iteration, and the same filler work per 8 MFMAs (MT = 2)\n");
         struct P { const char* name; kfn f; int mf; } ps[] = {{"16 MFMAs per filler set", k_step16, 16}, {"8 MFMAs per filler set", k_step8, 8},
-                                                              {"16 MFMAs, A through LDS", k_step16d, 16}};
+                                                              {"16 MFMAs, A through LDS", k_step16d, 16}, {"same, 8x unrolled", k_step128d, 128}, {"product memory mix", k_step16r, 16}, {" - global loads", k_r_nogl, 16},
+                                                              {" - ds_write_b128 (b32)", k_r_now4, 16}, {" - raw ds_read2", k_r_noraw, 16}, {" - all staging", k_r_nostg, 16}};
         for (const P& q : ps)
             for (int threads = 256; threads <= 512; threads += 256) {
                 unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
