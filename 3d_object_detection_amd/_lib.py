@@ -52,6 +52,7 @@ PROTOTYPES = {
     "pp_backbone": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "pp_head": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "pp_postprocess": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int, c_p]),
+    "pp_select_candidates": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "pp_infer_frame": (ctypes.c_int, [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
     "pp_infer_batch": (ctypes.c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i32), ctypes.c_int, c_p, c_p, ctypes.c_int, c_p]),
     "pp_fetch_frame_tensor": (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_int, c_p, c_p]),

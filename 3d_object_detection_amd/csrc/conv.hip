@@ -2494,29 +2494,34 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
         sc = pre_scale[c];
         sh = pre_shift[c];
     }
-    const float4* xi = reinterpret_cast<const float4*>(x + (size_t)c * HW);
-    float4* yo = reinterpret_cast<float4*>(y + (size_t)c * HW);
     float s = 0.f, q = 0.f;
     double ds = 0.0, dq = 0.0;
-    const int n4 = HW >> 2;
     int it = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        float4 v = xi[i];
-        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f);
-        v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
-        v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-        yo[i] = v;
-        s += (v.x + v.y) + (v.z + v.w);
-        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        if (++it == 8) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
-    }
-    if (blockIdx.x == 0 && (int)threadIdx.x < (HW & 3)) { // planes whose pixel count is no multiple of 4 (odd level-2 maps, e.g. 9 x 11)
-        const size_t e = (size_t)c * HW + ((size_t)n4 << 2) + threadIdx.x;
-        const float v = fmaxf(fmaf(x[e], sc, sh), 0.f);
-        y[e] = v;
-        s += v;
-        q += v * v;
+    if ((HW & 3) == 0) { // planes of every shipped configuration: 16-byte aligned rows of float4
+        const float4* xi = reinterpret_cast<const float4*>(x + (size_t)c * HW);
+        float4* yo = reinterpret_cast<float4*>(y + (size_t)c * HW);
+        const int n4 = HW >> 2;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+            float4 v = xi[i];
+            v.x = fmaxf(fmaf(v.x, sc, sh), 0.f);
+            v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
+            v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+            yo[i] = v;
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            if (++it == 8) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
+        }
+    } else { // odd planes (e.g. a 9 x 11 level-2 map): channel c starts at a 4-byte aligned address only -> scalar loop
+        const float* xi = x + (size_t)c * HW;
+        float* yo = y + (size_t)c * HW;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+            const float v = fmaxf(fmaf(xi[i], sc, sh), 0.f);
+            yo[i] = v;
+            s += v;
+            q += v * v;
+            if (++it == 32) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
+        }
     }
     ds += s;
     dq += q;
@@ -2654,6 +2659,7 @@ struct pp_net {
     float* ones = nullptr;
     float* zeros = nullptr;
     int num_cu = 256;
+    int w4_strips = -1; // PP_W4_STRIPS, read once at pp_create: -1 cost model, 0 never, 2 whenever whole main tiles exist (parity tests of the strip tiles)
 };
 
 const int kC[3] = {64, 128, 256};
@@ -3058,15 +3064,18 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         // 2.4 us per 8-channel chunk + 5 us of epilogue, and a strip launch adds its own rounds plus ~30 us of launch gap and
         // pipeline prologue (at batch 1 the 20 extra launches of a frame cost more than the empty tile area they save: 3.4 ms
         // against 2.2 ms per frame; at 16+ frames per launch the strips win: 979 against 1114 us on the 100 x 100 layers)
-        auto rounds = [&](int tiles) { return tiles > 0 ? pp_div_up((int64_t)tiles * ncb * B, net->num_cu) : 0; };
+        // The split is decided for the context's max_batch, NOT for the frames of this launch: full tiles and main + strip
+        // launches group the fp32 partial sums of the InstanceNorm statistics differently (~3e-5 on the logits), and a frame's
+        // result must not depend on how many frames ride in its pass.
+        const int plan_b = ctx->max_batch;
+        auto rounds = [&](int tiles) { return tiles > 0 ? pp_div_up((int64_t)tiles * ncb * plan_b, net->num_cu) : 0; };
         const int t_main = (mw / v.pw) * (mh / v.ph);
         const int t_right = Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0;
         const int t_bottom = Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0;
         const double tile_us = 2.4 * (L.cin / 8) + 5.0;
         const double full = rounds(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph)) * tile_us;
         const double split = (rounds(t_main) + rounds(t_right) + rounds(t_bottom)) * tile_us + 30.0 * ((t_right > 0) + (t_bottom > 0));
-        const char* strips_env = getenv("PP_W4_STRIPS"); // read per launch (tests switch it); 0: never, 2: whenever whole main tiles exist (parity tests of the strip tiles on small maps)
-        const bool no_strips = strips_env && strips_env[0] == '0', all_strips = strips_env && strips_env[0] == '2';
+        const bool no_strips = net->w4_strips == 0, all_strips = net->w4_strips == 2;
         if ((split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
             launch_region(v, 0, 0, mw, mh);
             if (Wout > mw) launch_region(sv, mw, 0, Wout, Hout);
@@ -3285,6 +3294,7 @@ int pp_net_create(pp_ctx* ctx)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) net->num_cu = prop.multiProcessorCount;
+        if (const char* e = getenv("PP_W4_STRIPS")) net->w4_strips = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : -1;
     }
     for (int l = 0; l < 3; ++l)
         for (int b = 0; b < 4; ++b)
@@ -3426,7 +3436,7 @@ int pp_net_commit(pp_ctx* ctx)
             PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(L.var.wino == 3 ? g1_lds(L.var, L.cin) : L.var.lds)));
             rc = pack_layer(ctx, L);
-            if (rc) return rc;
+            if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
         }
         if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); tune_cache_save(); }
     }

@@ -632,6 +632,20 @@ __global__ void __launch_bounds__(64 * PP_MAX_CLASSES) nms_reduce_b(const pp_pos
                     det_count + blockIdx.z * cnt_fs);
 }
 
+// stage entry pp_select_candidates: the sorted keys of post_topk as (anchor id, score) rows, -1 / 0 beyond a class's count
+__global__ void __launch_bounds__(256) post_export_sel(const uint64_t* __restrict__ sel, const int32_t* __restrict__ counters, int K,
+                                                       int32_t* __restrict__ idx, float* __restrict__ score, int32_t* __restrict__ count)
+{
+    const int c = blockIdx.x;
+    const int n = counters[c * 8 + 3];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const uint64_t k = i < n ? sel[(size_t)c * K + i] : 0ull;
+        idx[(size_t)c * K + i] = i < n ? (int32_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull)) : -1;
+        score[(size_t)c * K + i] = i < n ? __uint_as_float((uint32_t)(k >> 32)) : 0.f;
+    }
+    if (threadIdx.x == 0) count[c] = n;
+}
+
 } // namespace
 
 static int post_create_one(pp_ctx* ctx, pp_slot& S)
@@ -692,6 +706,34 @@ extern "C" int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, c
 {
     if (!ctx) return PP_E_ARG;
     return pp_postprocess_slot(ctx, 0, cls, box, dir, mask, det, det_count, nms_mode, (hipStream_t)stream_);
+}
+
+// Stage entry behind Inference.infer_torch (inference.py:140-189: per class mask gather, sigmoid, score threshold, top-k):
+// the first two stages of pp_postprocess alone.  idx i32[ncls][nms_pre_max] anchor ids by descending score (ties: lower
+// anchor id), score f32[ncls][nms_pre_max], count i32[ncls].
+extern "C" int pp_select_candidates(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
+                                    int32_t* idx, float* score, int32_t* count, void* stream_)
+{
+    if (!ctx) return PP_E_ARG;
+    if (!cls || !box || !dir || !mask || !idx || !score || !count) return pp_fail(ctx, PP_E_ARG, "pp_select_candidates: null pointer");
+    if (ctx->A == 0) return pp_fail(ctx, PP_E_STATE, "pp_select_candidates: call pp_set_anchors first");
+    hipStream_t stream = (hipStream_t)stream_;
+    pp_post* P = (pp_post*)ctx->slot[0].post;
+    const pp_config& c = ctx->cfg;
+    const int n = c.num_classes;
+    for (int i = 0; i < n; ++i)
+        if (c.class_end[i] > ctx->A) return pp_fail(ctx, PP_E_ARG, "class range exceeds anchor count");
+    PP_HIP(hipMemsetAsync(P->hist, 0, (size_t)n * (NBINS + 8) * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(post_filter, dim3(pp_div_up(P->cand_cap, 256 * FILTER_ITEMS), n), dim3(256), 0, stream, cls, mask, c, c.score_threshold,
+                       P->thr_bits, P->bin_shift, P->cand_cap, P->cand, P->counters, P->hist);
+    hipLaunchKernelGGL(post_thresh, dim3(n), dim3(1024), 0, stream, P->hist, P->counters, P->K);
+    hipLaunchKernelGGL(post_gather, dim3(pp_div_up(P->cand_cap, 256 * GATHER_ITEMS), n), dim3(256), 0, stream, P->cand, P->cand_cap, P->counters,
+                       P->thr_bits, P->bin_shift, P->shortl);
+    hipLaunchKernelGGL(post_topk, dim3(n), dim3(1024), 0, stream, c, P->cand, P->cand_cap, P->shortl, P->counters, P->K, box, dir,
+                       ctx->anchors, 0, P->sel, P->boxes, P->nbox, P->dirl);
+    hipLaunchKernelGGL(post_export_sel, dim3(n), dim3(256), 0, stream, P->sel, P->counters, P->K, idx, score, count);
+    PP_HIP(hipGetLastError());
+    return 0;
 }
 
 int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box, const float* dir, const uint8_t* mask, float* det,

@@ -32,9 +32,12 @@ int pp_stage_mark(pp_ctx* ctx, hipStream_t stream, int id)
         PP_HIP(hipEventCreate(&e));
         ctx->stage_ev.push_back(e);
         ctx->stage_id.push_back(-1);
+        ctx->stage_stream.push_back(nullptr);
     }
-    PP_HIP(hipEventRecord(ctx->stage_ev[ctx->stage_used], stream));
+    const hipError_t er = hipEventRecord(ctx->stage_ev[ctx->stage_used], stream);
+    if (er != hipSuccess) { ctx->stage_on = false; ctx->stage_used = 0; return pp_fail_hip(ctx, er, "hipEventRecord(stage mark)", __FILE__, __LINE__); }
     ctx->stage_id[ctx->stage_used] = id;
+    ctx->stage_stream[ctx->stage_used] = stream;
     ctx->stage_used++;
     return 0;
 }
@@ -51,16 +54,21 @@ extern "C" int pp_stage_profile_end(pp_ctx* ctx, double* ms_h)
 {
     if (!ctx || !ms_h) return PP_E_ARG;
     ctx->stage_on = false;
+    const size_t used = ctx->stage_used;
+    ctx->stage_used = 0; // whatever happens below, the next begin starts clean
     for (int i = 0; i < PP_ST_COUNT; ++i) ms_h[i] = 0.0;
-    for (size_t i = 0; i + 1 < ctx->stage_used; ++i) {
+    for (size_t i = 0; i + 1 < used; ++i) {
         const int id = ctx->stage_id[i];
         if (id < 0 || id >= PP_ST_COUNT) continue;
+        // an interval is meaningful only between two marks of ONE stream (the per-frame scheme, PP_BATCH_STAGES=0, marks
+        // post-processing on the slots' auxiliary streams: those pairs are skipped, not mis-timed)
+        if (ctx->stage_stream[i] != ctx->stage_stream[i + 1]) continue;
+        PP_HIP(hipEventSynchronize(ctx->stage_ev[i]));
         PP_HIP(hipEventSynchronize(ctx->stage_ev[i + 1]));
         float ms = 0.f;
         PP_HIP(hipEventElapsedTime(&ms, ctx->stage_ev[i], ctx->stage_ev[i + 1]));
         ms_h[id] += ms;
     }
-    ctx->stage_used = 0;
     return 0;
 }
 

@@ -108,6 +108,7 @@ struct pp_ctx {
     bool stage_on = false;
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> stage_id; // stage that FOLLOWS event i (-1: end of the pass)
+    std::vector<hipStream_t> stage_stream; // stream event i was recorded on (an interval needs both ends on one stream)
     size_t stage_used = 0;
 };
 // stage ids of pp_stage_mark / pp_stage_profile_end

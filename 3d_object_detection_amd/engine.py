@@ -317,6 +317,23 @@ class Engine:
                                                int(nms_mode), _stream()), self.ctx, "pp_postprocess")
         return det, cnt
 
+    def select_candidates(self, cls, box, dr, mask):
+        """Per class: anchors-mask gather, sigmoid, score threshold, exact top-k on the device (pp_select_candidates).
+        Returns idx i32[ncls, pre_max] (anchor ids by descending score, -1 padded), score f32[ncls, pre_max], count i32[ncls]."""
+        k, n = self.cfg.nms_pre_max, self.cfg.num_classes
+        idx = self._t((n, k), torch.int32)
+        score = self._t((n, k), torch.float32)
+        count = self._t((n,), torch.int32)
+        m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        _chk(cls.reshape(-1), torch.float32, (self.A,), "select_candidates: cls_preds")
+        _chk(box.reshape(-1), torch.float32, (self.A * 7,), "select_candidates: box_preds")
+        _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "select_candidates: dir_preds")
+        _chk(m.reshape(-1), torch.uint8, (self.A,), "select_candidates: anchors_mask")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pp_select_candidates(self.ctx, _ptr(cls), _ptr(box), _ptr(dr), _ptr(m), _ptr(idx), _ptr(score), _ptr(count),
+                                                     _stream()), self.ctx, "pp_select_candidates")
+        return idx, score, count
+
     def infer_frame(self, points, det=None, cnt=None, nms_mode=0):
         """Fused path: one call, no host sync.  points f32[N,4] on the device."""
         if det is None:

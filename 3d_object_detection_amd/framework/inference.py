@@ -2,9 +2,9 @@
 
 infer_gpu  -- the path the reference's loop calls (train.py:230): per-class score filter, top-k, decode, NMS, direction
               flip, range mask as ONE pp_postprocess call on the device and one D2H of <= ncls*300 rows.
-infer_torch -- the reference's second path (:140-256), stage by stage on the device like the original: torch indexing /
-              sigmoid / topk as the container plumbing the reference itself uses there, box decode / corners / stand-up
-              boxes / NMS through the HIP entry points (pp_box_decode, pp_corners2d, pp_standup2d, pp_nms).
+infer_torch -- the reference's second, staged path (:140-256) as a composition of the C ABI's stage entry points:
+              pp_select_candidates (mask gather + sigmoid + threshold + top-k for all classes in one call), pp_box_decode,
+              pp_corners2d, pp_standup2d, pp_nms; torch only indexes the <= ncls*1000 selected rows.
 Both advance the reference's accumulators p1..p4 (train.py:244-258 prints them per frame)."""
 import time
 
@@ -104,77 +104,60 @@ class Inference:
         return [anno]
 
     def infer_torch(self, example, preds_dict):
-        """inference.py:140-256, stage by stage with the same four synchronised buckets per class."""
-        cls_all = preds_dict["cls_preds"].squeeze(0)
-        box_all = preds_dict["box_preds"].squeeze(0)
-        dir_all = preds_dict["dir_preds"].squeeze(0)
-        anchors_mask = example["anchors_mask"].squeeze(0)
-        name_list, location_list, dimensions_list, rotation_y_list, score_list = [], [], [], [], []
-        sync = torch.cuda.synchronize if cls_all.is_cuda else (lambda: None)
-        for cls, a_range in self.class_masks.items():
-            sync()
-            start = time.time()
-            a_mask = anchors_mask[a_range[0]: a_range[1]]
-            box_preds = box_all[a_range[0]: a_range[1]][a_mask]
-            cls_preds = cls_all[a_range[0]: a_range[1]][a_mask]
-            dir_preds = dir_all[a_range[0]: a_range[1]][a_mask]
-            anchors = self.anchors[a_range[0]: a_range[1]][a_mask]
-            cls_scores = torch.sigmoid(cls_preds)
-            top_scores = torch.max(cls_scores, dim=-1)[0]
-            dir_labels = torch.max(dir_preds, dim=-1)[1]
-            selected = None
-            p1 = p2 = p3 = start
-            keep = top_scores >= self._nms_score_threshold
-            if keep.any():
-                top_scores, box_preds, dir_labels, anchors = top_scores[keep], box_preds[keep], dir_labels[keep], anchors[keep]
-                pre_max_size = min(top_scores.shape[0], self._nms_pre_max_size)
-                sync()
-                p1 = time.time()
-                top_scores, indices = torch.topk(top_scores, k=pre_max_size)
-                box_preds, dir_labels, anchors = box_preds[indices], dir_labels[indices], anchors[indices]
-                sync()
-                p2 = time.time()
-                box_preds = box_torch_ops.box_decode(box_preds, anchors)
-                boxes_for_nms = box_preds[:, [0, 1, 3, 4, 6]]
-                corners = box_torch_ops.center_to_corner_box2d(boxes_for_nms[:, :2], boxes_for_nms[:, 2:4], boxes_for_nms[:, 4])
-                boxes_for_nms = box_torch_ops.corner_to_standup_nd(corners)
-                sync()
-                p3 = time.time()
-                selected = nms_torch(boxes_for_nms, top_scores, pre_max_size=self._nms_pre_max_size,
-                                     post_max_size=self._nms_post_max_size, iou_threshold=self._nms_iou_threshold)
-                if selected is not None:
-                    selected = selected.to(box_preds.device)
-            sync()
-            p4 = time.time()
-            if selected is not None:
-                box_preds = box_preds[selected]
-                scores_preds = top_scores[selected]
-                opp_labels = (box_preds[..., -1] > 0) ^ dir_labels[selected].bool()
-                box_preds[..., -1] += torch.where(opp_labels, torch.tensor(np.pi).type_as(box_preds), torch.tensor(0.0).type_as(box_preds))
-                scores_preds = scores_preds.detach().cpu().numpy()
-                box_preds = box_preds.detach().cpu().numpy()
-                limit_range = self.center_limit
-                range_mask = np.any(box_preds[:, :3] > limit_range[:3], axis=1) & np.any(box_preds[:, 3:6] < limit_range[3:], axis=1)
-                box_preds = box_preds[range_mask]
-                r = box_preds[..., -1]
-                box_preds[..., -1] = r - np.floor(r / (2 * np.pi) + 0.5) * (2 * np.pi)  # box_np_ops.limit_period(r, 0.5, 2*pi)
-                scores_preds = scores_preds[range_mask]
-                dt_num = box_preds.shape[0]
-                if dt_num > 0:
-                    name_list.append(np.full(dt_num, cls, dtype='<U10'))
-                    location_list.append(box_preds[:, :3])
-                    dimensions_list.append(box_preds[:, 3:6])
-                    rotation_y_list.append(box_preds[:, 6])
-                    score_list.append(scores_preds)
-            self.p1 += p1 - start
-            self.p2 += p2 - p1
-            self.p3 += p3 - p2
-            self.p4 += p4 - p3
+        """The reference's staged post-processing (inference.py:140-256) as a composition of the engine's stage entry points,
+        all classes at once where the stage allows it:
+          p1  pp_select_candidates -- per class mask gather, sigmoid, score >= 0.05, exact top-1000 in ONE device call
+              (the reference's p1 and p2 buckets; its boolean-mask indexing over up to 960 k rows per class is gone);
+          p2  gather of the <= ncls*1000 selected rows (box / dir logits, anchors);
+          p3  pp_box_decode, pp_corners2d, pp_standup2d on the concatenated candidates of all classes;
+          p4  pp_nms per class (NMS is per class by definition), then direction flip, the range-mask quirk
+              (:107-109 compares dims with the upper limits) and limit_period on the kept rows, one D2H."""
+        eng = engine_for(self._config)
+        dev = eng.device
+        tick = (lambda: (torch.cuda.synchronize(), time.time())[1]) if self.profile_stages else time.time
+        t0 = tick()
+        box_all = preds_dict["box_preds"].contiguous().view(-1, 7)
+        dir_all = preds_dict["dir_preds"].contiguous().view(-1, 2)
+        idx, score, count = eng.select_candidates(preds_dict["cls_preds"].contiguous(), box_all, dir_all,
+                                                  example["anchors_mask"].reshape(-1).contiguous())
+        counts = count.cpu().tolist()
+        t1 = tick()
+        live = torch.arange(idx.shape[1], device=dev)[None, :] < count[:, None]
+        rows = idx[live].long()            # class-major, descending score inside a class
+        scores = score[live]
+        enc, anc = box_all[rows], self.anchors[rows]
+        dir_label = dir_all[rows, 1] > dir_all[rows, 0]
+        t2 = tick()
+        dec = box_torch_ops.box_decode(enc, anc) if rows.numel() else enc
+        standup = (box_torch_ops.corner_to_standup_nd(box_torch_ops.center_to_corner_box2d(dec[:, :2], dec[:, 3:5], dec[:, 6]))
+                   if rows.numel() else dec[:, :4])
+        t3 = tick()
+        kept, kept_cls, off = [], [], 0
+        for ci, n in enumerate(counts):
+            sel = nms_torch(standup[off:off + n], scores[off:off + n], pre_max_size=self._nms_pre_max_size,
+                            post_max_size=self._nms_post_max_size, iou_threshold=self._nms_iou_threshold) if n else None
+            if sel is not None:
+                kept.append(sel.to(dev) + off)
+                kept_cls.append(torch.full((sel.numel(),), ci, dtype=torch.int64))
+            off += n
         anno = get_start_result_anno()
-        if len(name_list) > 0:
-            anno["name"] = np.concatenate(name_list)
-            anno["location"] = np.concatenate(location_list)
-            anno["dimensions"] = np.concatenate(dimensions_list)
-            anno["rotation_y"] = np.concatenate(rotation_y_list)
-            anno["score"] = np.concatenate(score_list)
+        if kept:
+            k = torch.cat(kept)
+            out = dec[k].clone()
+            out[:, 6] += torch.where((out[:, 6] > 0) ^ dir_label[k], torch.tensor(np.pi, dtype=out.dtype, device=dev), torch.zeros((), dtype=out.dtype, device=dev))
+            out = out.cpu().numpy()
+            sc = scores[k].cpu().numpy()
+            ci = torch.cat(kept_cls).numpy()
+            lim = np.asarray(self.center_limit)
+            ok = np.any(out[:, :3] > lim[:3], axis=1) & np.any(out[:, 3:6] < lim[3:], axis=1)
+            out, sc, ci = out[ok], sc[ok], ci[ok]
+            out[:, 6] -= np.floor(out[:, 6] / (2 * np.pi) + 0.5) * (2 * np.pi)  # box_np_ops.limit_period(r, 0.5, 2*pi)
+            if out.shape[0]:
+                names = np.array(list(self.class_masks.keys()), dtype='<U10')
+                anno.update(name=names[ci], location=out[:, :3], dimensions=out[:, 3:6], rotation_y=out[:, 6], score=sc)
+        t4 = tick()
+        self.p1 += t1 - t0
+        self.p2 += t2 - t1
+        self.p3 += t3 - t2
+        self.p4 += t4 - t3
         return [anno]

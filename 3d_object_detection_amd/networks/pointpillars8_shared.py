@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from ..engine import engine_for
-from .. import synth
+from .init import init_state_dict
 
 
 class PointPillars:
@@ -21,7 +21,7 @@ class PointPillars:
         self.profile_stages = True  # the reference synchronises after every stage (:365-374)
         self.pfn_time, self.rpn_time, self.scatter_time, self.heads_time = 0.0, 0.0, 0.0, 0.0
         # like nn.Module construction, start from random initial weights
-        self.load_state_dict(synth.seeded_state_dict(0, norm=self._norm))
+        self.load_state_dict(init_state_dict(0, norm=self._norm))
 
     # nn.Module-style surface used by train.py:196-205
     def to(self, device):

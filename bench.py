@@ -14,8 +14,9 @@ Two timed regions of K steps each, both bracketed by barrier + synchronize, max 
   * `value_host_start` -- SURVEY 8(d)'s timer, the one train.py:223-237 uses: clouds start in pinned HOST memory, their
                           H2D copies run inside the region (copy stream, double-buffered, overlapping the previous pass),
                           the region ends when the last detection record is on the host.
-Frames are sharded by index across ranks with no data-path collective; RCCL only gathers the detection records once
-at the end of a region (one all_gather).  Default: weak scaling, `--batch` frames per rank per step.
+Frames are sharded by index across ranks with no data-path collective; RCCL only gathers the detection records, one
+all_gather per step inside the timed loop (stream-ordered behind the step's kernels).  Default: weak scaling, `--batch`
+frames per rank per step.
 `--global-batch G` (BASELINE config 5: G = 64) fixes the TOTAL frames per step and shards them, strong scaling.
 Rank 0 prints ONE JSON line with `roofline` (dominant conv kernel timed with HIP events on its launch stream inside
 the resident region; `frac` = EXECUTED MFMA flops / fp32-MFMA peak; per-stage HBM rooflines under `stages`) and, at
@@ -249,9 +250,14 @@ def main():
     frames_per_step = args.global_batch if args.global_batch > 0 else world * NB
     MAXB = 32  # frames per pp_infer_batch pass; a rank with more frames per step runs several passes
     passes = [mine[i:i + MAXB] for i in range(0, NB, MAXB)] if NB else []
+    # every rank builds its engine for the SAME max_batch -- the busiest rank's frame count (a global batch the world size does
+    # not divide gives the ranks different counts): the tuner's key and the Winograd strip decision carry it, so rank 0's
+    # table fits every rank and all ranks run identical kernels
+    NB_MAX = shard.frames_per_rank_max(world, args.global_batch) if args.global_batch > 0 else NB
+    ENG_B = max(1, min(NB_MAX, MAXB))
 
     def make_engine():
-        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=max(1, min(NB, MAXB)), **({} if stub else {"precision": args.precision}))
+        e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=ENG_B, **({} if stub else {"precision": args.precision}))
         e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
         return e
 
@@ -284,6 +290,12 @@ def main():
             o += len(p)
         det_h[j].copy_(det[j], non_blocking=True)
         cnt_h[j].copy_(cnt[j], non_blocking=True)
+        if dist:
+            # the one collective of the path, once per STEP and stream-ordered behind the step's kernels: this rank's NB
+            # records, zero-padded to the busiest rank's count (a rank without frames still takes part)
+            gathered[0] = shard.gather_detections(det[j, :NB], cnt[j, :NB], pad_to=NB_MAX)
+
+    gathered = [None]
 
     def step_resident(i, j):
         with D.use_stream(compute):
@@ -315,9 +327,6 @@ def main():
         t0 = time.perf_counter()
         for i in range(K):
             step(i, i)
-        if dist:
-            D.wait_stream(D.current_stream(dev), compute)  # the one collective of the path follows the compute it gathers
-            shard.gather_detections(det.view(K * max(NB, 1), rows, 9), cnt.view(K * max(NB, 1), ncnt))
         D.synchronize()
         if dist:
             dist.barrier()
@@ -358,7 +367,8 @@ def main():
                                    f"(mean {int(np.mean([c.shape[0] for c in clouds])) if clouds else 0} points, one distinct cloud per frame of a step), "
                                    "independent frames (batch=1 semantics), random-init weights (InstanceNorm backbone), AABB NMS; "
                                    "`value`: clouds resident in HBM; `value_host_start`: clouds in pinned host memory, H2D inside the timed region (SURVEY 8(d) timer)",
-                       "frames_per_step": frames_per_step, "frames_per_pass_per_gpu": min(NB, MAXB), "parallelism": f"frame-sharded x{world}",
+                       "frames_per_step": frames_per_step, "frames_per_pass_per_gpu": min(NB, MAXB), "engine_max_batch": ENG_B,
+                       "parallelism": f"frame-sharded x{world}" + (", one all_gather of detection records per step" if world > 1 else ""),
                        "global_batch": args.global_batch or None, "cls_bias": args.cls_bias, "mean_detections": mean_det},
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0

@@ -108,6 +108,12 @@ int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box, float* di
 int pp_postprocess(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
                    float* det, int32_t* det_count, int nms_mode, void* stream);
 
+/* First half of pp_postprocess as a stage of its own, behind Inference.infer_torch (inference.py:140-189: per class
+ * mask gather, sigmoid, score >= 0.05, top-nms_pre_max).  idx i32[num_classes][nms_pre_max] anchor ids by descending score
+ * (ties: lower anchor id; -1 beyond a class's count), score f32[num_classes][nms_pre_max], count i32[num_classes]. */
+int pp_select_candidates(pp_ctx* ctx, const float* cls, const float* box, const float* dir, const uint8_t* mask,
+                         int32_t* idx, float* score, int32_t* count, void* stream);
+
 /* Fused frame: voxelise -> mask -> PFN -> BEV -> backbone -> head -> post-process, no host sync. */
 int pp_infer_frame(pp_ctx* ctx, const float* pts, int n, float* det, int32_t* det_count, int nms_mode, void* stream);
 

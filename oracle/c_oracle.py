@@ -21,6 +21,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.orc_rotated_iou.restype = ctypes.c_float
+        _lib.orc_min_margin.restype = ctypes.c_double
     return _lib
 
 
@@ -85,3 +86,23 @@ def rotated_iou_eval(boxes, qboxes, criterion=-1):
     if b.shape[0] and q.shape[0]:
         lib().orc_rotated_iou_eval(_p(b, ctypes.c_float), b.shape[0], _p(q, ctypes.c_float), q.shape[0], int(criterion), _p(out, ctypes.c_float))
     return out.astype(dt)
+
+
+class numba_typing:
+    """Context manager: the NMS routines follow numba's typing of the reference's device functions (`float32 + 1` and
+    `/ 2.0` promote to float64 -- see pp_oracle.c) instead of the all-fp32 arithmetic the golden vectors pin.  `.margin`
+    after the block = the smallest |IoU - threshold| any NMS run inside it has seen."""
+
+    def __init__(self, on=True):
+        self.on = on
+        self.margin = None
+
+    def __enter__(self):
+        lib().orc_set_numba_typing(1 if self.on else 0)
+        lib().orc_reset_min_margin()
+        return self
+
+    def __exit__(self, *exc):
+        self.margin = float(lib().orc_min_margin())
+        lib().orc_set_numba_typing(0)
+        return False

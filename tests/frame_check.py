@@ -65,9 +65,15 @@ def _angle_dev(a, b):
     return np.abs(d)
 
 
-def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_tol=TOL):
+DISCONT = "iou-discontinuous-in-reference-arithmetic"
+
+
+def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_tol=TOL, max_explained=None, max_discontinuous=2):
     """ref / gpu: dicts with cls[A], box[A,7], dir[A,2], mask[A] (+ anchors, class_masks, center_limit in ref).
-    det_gpu f32[k,9], cnt_gpu int[1+ncls].  Returns the report dict; raises AssertionError on any violation."""
+    det_gpu f32[k,9], cnt_gpu int[1+ncls].  Returns the report dict; raises AssertionError on any violation.
+    The explained differences are BOUNDED: at most `max_explained` rows per frame (default max(4, 0.5 % of the reference's rows)),
+    at most `max_discontinuous` of them through the rotated-IoU discontinuity branch (0 in AABB mode by construction); the
+    per-reason counts are returned in rep["reasons"] and printed, so a jump is visible."""
     rotated = nms_mode in ("rotated", 1)
     mode = "rotated" if rotated else "aabb"
     nms_fn = C.nms_rotated if rotated else C.nms_aabb
@@ -175,8 +181,12 @@ def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_t
                         scale = max(1.0, float(np.abs(ra[:4]).max()), float(np.abs(rb_[:4]).max()))
                         if max(float(np.abs(ra[:5] - ga[:5]).max()), float(np.abs(rb_[:5] - gb[:5]).max())) > TOL * scale:
                             continue
+                        # only a box that one of the two NMS runs KEPT (or whose own flip is already explained) can have
+                        # suppressed a: a dropped b proves nothing
+                        if not (b in kept_r or b in kept_g or done.get(b)):
+                            continue
                         if (C.rotated_iou(ra[:5], rb_[:5]) > IOU_THR) != (C.rotated_iou(ga[:5], gb[:5]) > IOU_THR):
-                            reason = "iou-discontinuous-in-reference-arithmetic"
+                            reason = DISCONT
                             break
             else:  # survived both NMS runs, differs after the 300 cut / range mask
                 if any(done.get(b) and score(b) >= s_a - eps_s for b in S if b != a):
@@ -199,12 +209,29 @@ def compare_frame(ref, gpu, det_gpu, cnt_gpu, nms_mode="aabb", label="", logit_t
                                                                                cand=(a in cand_r, a in cand_g), kept=(a in kept_r, a in kept_g),
                                                                                eps_s=eps_s, eps_iou=eps_iou, iou_thr=IOU_THR,
                                                                                higher_scored_overlaps=near)))
-    rep.update(matched=matched, max_matched_dev=max_dev, differing=differing, explained=explained, why=why[:12])
+    reasons = {}
+    for w in why:
+        reasons[w[2]] = reasons.get(w[2], 0) + 1
+    rep.update(matched=matched, max_matched_dev=max_dev, differing=differing, explained=explained, why=why[:12], reasons=reasons)
     assert explained == differing, (label, rep)
-    print(f"[frame parity] {label}: ref {rep['n_ref']} / gpu {rep['n_gpu']} detections, {matched} matched by anchor id (max dev {max_dev:.2e}), "
-          f"{differing} differing rows all explained {sorted(set(w[2] for w in why))}; logit dev cls {rep['dev_cls']:.2e} box {rep['dev_box']:.2e} "
-          f"dir {rep['dev_dir']:.2e}; post-proc on own logits dev {rep['post_self_dev']:.1e}")
+    cap = max(4, int(np.ceil(0.005 * rep["n_ref"]))) if max_explained is None else max_explained
+    assert differing <= cap, (label, f"{differing} differing rows exceed the cap of {cap}", reasons)
+    assert reasons.get(DISCONT, 0) <= (max_discontinuous if rotated else 0), (label, "too many rows explained by the IoU discontinuity", reasons)
+    line = (f"[frame parity] {label}: ref {rep['n_ref']} / gpu {rep['n_gpu']} detections, {matched} matched by anchor id (max dev {max_dev:.2e}), "
+            f"{differing} differing rows all explained {reasons}; logit dev cls {rep['dev_cls']:.2e} box {rep['dev_box']:.2e} "
+            f"dir {rep['dev_dir']:.2e}; post-proc on own logits dev {rep['post_self_dev']:.1e}")
+    print(line)
+    report(line)
     return rep
+
+
+def report(line):
+    """Append a line to $PP_PARITY_REPORT (the GPU run collects it into profiles/rNN_parity_report.txt)."""
+    import os
+    path = os.environ.get("PP_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
 
 
 def gpu_logits(eng, frame):

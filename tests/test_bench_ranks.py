@@ -50,6 +50,15 @@ def test_global_batch_strong_scaling_flow():
     assert out["config"]["frames_per_pass_per_gpu"] == 3
 
 
+def test_global_batch_not_divisible_and_idle_rank():
+    """a global batch the world size does not divide (5 = 3 + 2) and one that leaves a rank without frames (1):
+    every rank builds its engine for the busiest rank's frame count and pads its records, the per-step gather completes."""
+    out = run_bench(2, ["--global-batch", "5"])
+    assert out["config"]["frames_per_step"] == 5 and out["config"]["engine_max_batch"] == 3 and out["value"] > 0
+    out = run_bench(2, ["--global-batch", "1"])
+    assert out["config"]["frames_per_step"] == 1 and out["config"]["engine_max_batch"] == 1 and out["value"] > 0
+
+
 def test_tuning_is_shared_not_repeated():
     """share_tuning: a rank that is not the source imports the source's table before it builds its engine."""
     import importlib

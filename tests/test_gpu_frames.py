@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import golden, load_pkg
-from frame_check import compare_frame, gpu_logits, oracle_frame
+from frame_check import DISCONT, compare_frame, gpu_logits, oracle_frame, report
 from oracle import c_oracle as C
 from oracle import pp_oracle as O
 
@@ -36,7 +36,9 @@ def check_golden_samples(g, rpn, cls, box, dr, feat, tol):
         "box": float(np.abs(box.reshape(-1, 7)[g["pred_idx"]] - g["box_vals"]).max()),
         "dir": float(np.abs(dr.reshape(-1, 2)[g["pred_idx"]] - g["dir_vals"]).max()),
     }
-    print("[golden samples] max abs deviation from the reference:", {k: f"{v:.2e}" for k, v in dev.items()})
+    line = "[golden samples] max abs deviation from the reference: " + str({k: f"{v:.2e}" for k, v in dev.items()})
+    print(line)
+    report(line)
     assert dev["pfn"] <= 2e-5 and max(dev["rpn"], dev["cls"], dev["box"], dev["dir"]) <= tol, dev
     return dev
 
@@ -137,6 +139,58 @@ def test_batched_sparse_path_vs_reference(tag, synth, eight_ref):
     check_golden_samples(g, eng.fetch(1, "rpn").cpu().numpy(), gl["cls"], gl["box"], gl["dir"], eng.fetch(1, "feat").cpu().numpy(), 1e-4)
     compare_frame(r, gl, det, cnt, "aabb", f"batched sparse eight_20cm {tag}")
     assert int(cnt_b[2, 0]) == 0
+
+
+@pytest.mark.parametrize("nb", [32, 8])
+def test_bench_plan_vs_oracle(nb, synth, eight_ref):
+    """The launch plan bench.py times, pinned to the oracle: Engine(max_batch = frames per pass) exactly as bench.py builds it
+    (max_batch 32: the default bench pass, tuned at 16 frames per launch; 8: the per-GPU shape of BASELINE config 5, 64 frames
+    over 8 GPUs), nb distinct clouds with the golden cloud (seed 1000) at positions 0 and nb - 1, both against the oracle's
+    logits / detections and the reference's own sampled values.  The tilings that ran are printed (compare `extras.tilings`
+    of the bench line).  Reference loop: train.py:219-242."""
+    pts, refs = eight_ref
+    sd, r = refs["rand"]  # bench.py: seeded_state_dict(0), no cls bias
+    g = golden("e2e_eight_20cm_rand")
+    eng_mod = load_pkg("engine")
+    eng = eng_mod.Engine(make_cfg(synth, "eight_20cm"), max_batch=nb)
+    eng.load_state_dict(sd)
+    plan = [t["tiling"] for t in eng.layer_tilings()]
+    line = f"[bench plan] max_batch {nb}: " + " | ".join(plan)
+    print(line)
+    report(line)
+    gold = torch.from_numpy(pts).cuda()
+    clouds = [gold] + [torch.from_numpy(synth.lidar_cloud("eight_20cm", seed=1000 + f)).cuda() for f in range(1, nb - 1)] + [gold]
+    assert len(clouds) == nb
+    det_b, cnt_b = eng.infer_batch(clouds)
+    det_b, cnt_b = det_b.cpu().numpy(), cnt_b.cpu().numpy()
+    for f in (0, nb - 1):
+        gl = gpu_logits(eng, f)
+        check_golden_samples(g, eng.fetch(f, "rpn").cpu().numpy(), gl["cls"], gl["box"], gl["dir"], eng.fetch(f, "feat").cpu().numpy(), 1e-4)
+        compare_frame(r, gl, det_b[f, :cnt_b[f, 0]], cnt_b[f], "aabb", f"bench plan max_batch {nb}, frame {f}")
+    # the two copies of the golden cloud ride at opposite ends of the pass (different stage groups at 32): same result
+    assert np.array_equal(cnt_b[0], cnt_b[nb - 1])
+    np.testing.assert_allclose(det_b[0, :cnt_b[0, 0], :8], det_b[nb - 1, :cnt_b[0, 0], :8], rtol=0, atol=1e-5 * 300)
+    # every frame of the pass produced detections (no frame silently skipped)
+    assert (cnt_b[:, 0] > 0).all()
+
+
+def test_rotated_nms_trained_like_box_regime(synth):
+    """Rotated NMS with a box head scaled so that decoded sizes stay in a trained detector's regime (< 20 m): the checker's
+    rotated-IoU discontinuity branch -- needed for the 100 m boxes of a random-init head -- must not fire at all here."""
+    eng_mod = load_pkg("engine")
+    sd = dict(synth.seeded_state_dict(2, cls_bias=-3.0))
+    for k in ("heads.conv_box.weight", "heads.conv_box.bias"):
+        sd[k] = sd[k] * 0.05
+    eng = eng_mod.Engine(make_cfg(synth, "eight_20cm"))
+    eng.load_state_dict(sd)
+    pts = synth.lidar_cloud("eight_20cm", seed=91)
+    det, cnt = eng.infer_frame(torch.from_numpy(pts).cuda(), nms_mode=1)
+    cnt = cnt.cpu().numpy()
+    rows = det[:cnt[0]].cpu().numpy()
+    assert rows.shape[0] > 50 and float(rows[:, 3:6].max()) < 20.0
+    r = oracle_frame(synth, "eight_20cm", pts, sd)
+    rep = compare_frame(r, gpu_logits(eng, 0), rows, cnt, 1, "fused eight_20cm rotated NMS, trained-like box regime", max_discontinuous=0)
+    assert rep["reasons"].get(DISCONT, 0) == 0
 
 
 @pytest.mark.parametrize("name,norm,nms_mode,bias", [("eight_20cm", "instance", 1, -3.0), ("nuscene", "batch", 0, -3.0),

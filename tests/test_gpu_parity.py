@@ -422,7 +422,7 @@ def test_batched_frames_equal_single_frames(fw, synth):
     assert int(cnt_b[2, 0]) == 0
 
 
-def _assert_rows_close(a, b, rel=1e-4):
+def _assert_rows_close(a, b, rel=1e-5):
     """Detection rows [x y z w l h r score label] equal up to `rel` of the row's largest extent (the decode multiplies
     the logit noise by the anchor diagonal / exponentiates it), angles compared modulo 2 pi, labels exactly."""
     assert a.shape == b.shape
@@ -441,9 +441,10 @@ def test_full_size_batch_properties(fw, synth):
     """BASELINE.json's metric workload (eight_20cm, 800x800 BEV) at a batch that spans TWO stage groups
     (PP_GROUP = 16 frames per integer-stage launch -> 18 frames = 16 + 2), ragged clouds and one empty
     frame.  Size-independent properties instead of the (too slow) oracle: frame independence (each frame of
-    the batch equals its own pp_infer_frame; counts bit-exact, boxes to 1e-4 of the row's extent), permutation
-    equivariance and repeatability of the same call (both within 1e-5: same tiling, only the order of the fp64
-    statistics atomics moves)."""
+    the batch equals its own pp_infer_frame; counts bit-exact, boxes to 1e-5 of the row's extent, logits to 1e-5), permutation
+    equivariance and repeatability of the same call (all within 1e-5: the launch plan of a context -- tilings AND the
+    Winograd main / strip split -- is fixed for its max_batch, not for the frames of a pass, so only the order of the fp64
+    statistics atomics and the per-wave grouping of the 1x1 GEMMs' fp32 partial sums move)."""
     eng_mod = load_pkg("engine")
     cfg = make_cfg(synth, "eight_20cm")
     fw["vg"].VoxelGenerator(cfg)
@@ -458,9 +459,8 @@ def test_full_size_batch_properties(fw, synth):
     det_b, cnt_b = det_b.cpu().numpy().copy(), cnt_b.cpu().numpy().copy()
     assert int(cnt_b[17, 0]) == 0
     assert (cnt_b[:3, 0] > 0).all()
-    # frame independence, on both sides of the group boundary.  A batch of 18 and a batch of 1 may be tiled
-    # differently (launch_conv's strip decision depends on the tile count), which regroups the fp32 partial sums of
-    # the InstanceNorm statistics: logits agree to ~3e-5, and the decoded boxes to that times the row's extent.
+    # frame independence, on both sides of the group boundary (round 2 needed 1e-4 here: launch_conv chose full tiles or
+    # main + strip launches by the frames of the pass, which regrouped the InstanceNorm partial sums by ~3e-5)
     logits_b = {i: {k: eng.fetch(i, k).cpu().numpy() for k in ("cls", "box", "dir")} for i in (0, 16)}
     for i in (0, 3, 5, 15, 16, 17):
         d1, c1 = eng.infer_frame(clouds[i])
@@ -469,7 +469,7 @@ def test_full_size_batch_properties(fw, synth):
         _assert_rows_close(det_b[i, :k], d1[:k].cpu().numpy())
         if i in logits_b:
             for name, t in logits_b[i].items():
-                np.testing.assert_allclose(eng.fetch(0, name).cpu().numpy(), t, rtol=0, atol=1e-4, err_msg=f"{name} of frame {i}")
+                np.testing.assert_allclose(eng.fetch(0, name).cpu().numpy(), t, rtol=0, atol=1e-5, err_msg=f"{name} of frame {i}")
     # permutation equivariance: reversing the frame order reverses the outputs
     det_r, cnt_r = eng.infer_batch(clouds[::-1])
     det_r, cnt_r = det_r.cpu().numpy(), cnt_r.cpu().numpy()

@@ -36,9 +36,13 @@ def _worker(rank, world, port, n_frames, out):
         cnt[j, 0] = k
     t0 = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t0, op=dist.ReduceOp.MAX)  # the max-over-ranks timing of bench.py
-    dets, cnts = shard.gather_detections(det, cnt)
+    # the documented pad (every rank can compute it) and the discovered one must agree
+    dets, cnts = shard.gather_detections(det, cnt, pad_to=shard.frames_per_rank_max(world, n_frames))
+    dets2, cnts2 = shard.gather_detections(det, cnt)
+    same = all(torch.equal(a, b) for a, b in zip(dets, dets2)) and all(torch.equal(a, b) for a, b in zip(cnts, cnts2))
+    same &= [d.shape[0] for d in dets] == [len(shard.frames_for_rank(r, world, n_frames)) for r in range(world)]
     merged = shard.merge_in_frame_order(dets, cnts, n_frames)
-    ok = abs(float(t0) - 0.1 * world) < 1e-12
+    ok = abs(float(t0) - 0.1 * world) < 1e-12 and same
     for f, (d, c) in enumerate(merged):
         ok &= d.shape[0] == f % rows and bool((d == float(f)).all()) and int(c[0]) == f % rows
     out[rank] = bool(ok)
@@ -54,6 +58,16 @@ def test_frame_sharding_world2():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 8, out), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+def test_unequal_and_empty_shards_world2():
+    """A global batch that the world size does not divide (5 frames: 3 + 2) and one smaller than the world (1 frame: rank 1
+    holds nothing): the padded gather must deliver every frame and trim every rank to its own count."""
+    for n_frames in (5, 1):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), n_frames, out), nprocs=2, join=True)
+        assert out[0] and out[1], n_frames
 
 
 def test_single_process_gather_is_identity():
