@@ -32,104 +32,11 @@
 #include <cstring>
 #include <unistd.h>
 #include "pp_common.h"
+#include "conv_common.h"
 
 namespace {
 
-// Workgroups of a launch are dealt round-robin over the 8 XCDs in linear-id order (x fastest), each XCD with
-// its own 4 MB L2.  Re-number them so that XCD k works through the k-th CONTIGUOUS eighth of the
-// (cout-block fastest, then tile, then frame) order: the cout blocks of one tile (same input patch) and
-// neighbouring tiles (shared halo lines) then meet in one L2 instead of each fetching across the fabric.
-struct BlockId { int x, y, z; };
-__device__ __forceinline__ BlockId xcd_block_id()
-{
-    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-    const unsigned n = gx * gy * gz;
-    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned per = n >> 3;
-    const unsigned l2 = (lin < per * 8) ? (lin & 7) * per + (lin >> 3) : lin;
-    BlockId b;
-    b.y = (int)(l2 % gy);
-    const unsigned t = l2 / gy;
-    b.x = (int)(t % gx);
-    b.z = (int)(t / gx);
-    return b;
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// dword-aligned vector stores (global memory takes multi-dword accesses at dword alignment)
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-
-// Sum over the 16 lanes that share lane >> 4 (one row of the 16x16 MFMA tile = one DPP row), on the VALU: two quad
-// permutes, row_half_mirror, row_mirror.  After each step all lanes of the merged group hold the same value, so the
-// result is bit-identical to the xor-shuffle butterfly (1, 2, 4, 8) it replaces -- which hipcc turned into four
-// dependent ds_bpermute per value (64 LDS round trips per Winograd tile and wave).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += dpp_f32<0xB1>(v);  // quad_perm [1,0,3,2]
-    v += dpp_f32<0x4E>(v);  // quad_perm [2,3,0,1]
-    v += dpp_f32<0x141>(v); // row_half_mirror
-    v += dpp_f32<0x140>(v); // row_mirror
-    return v;
-}
-
-constexpr int NREP = 8; // replicated statistics accumulators (spreads atomic contention)
-
-// compile-time for: f(integral_constant<int, I>) for I in [B, E)
-template <int B, int E, typename F>
-__device__ __forceinline__ void pp_steps(F&& f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        pp_steps<B + 1, E>(f);
-    }
-}
-
-enum { EPI_PLAIN = 0, EPI_UP2 = 1, EPI_UP4 = 2, EPI_HEAD = 3 };
-enum { PRE_RAW = 0, PRE_STATS = 1, PRE_AFFINE = 2 };
-
-struct ConvP {
-    const float* in;
-    const float* w;   // packed [cout_block][chunk][tap][kc][BM]
-    float* out;
-    const float* res; // residual, same layout as out (nullable)
-    int Cin, Hin, Win;
-    int Cout;         // rows of the GEMM (virtual channels for deconv, 96 for the head)
-    int Hout, Wout;   // pixel grid of the GEMM
-    int pre;
-    const double* pre_acc; // [NREP][Cin][2]
-    const float* pre_scale;
-    const float* pre_shift;
-    double pre_inv_n;
-    float eps;
-    double* stat_acc; // [NREP][Cstat][2] (nullable)
-    int stat_C;       // channels in stat_acc
-    // head
-    const float* bias;
-    float* out_box;
-    float* out_dir;
-    int n_cls, n_box; // na, 7 na (dir = rest up to n_rows) for na anchors per location (reference: 9, 63)
-    int n_rows;       // 10 na (reference: 90)
-    int dbg;          // diagnostics only (PP_CONV_DBG): 1 = skip staging after chunk 0, 4 = skip epilogue
-    // batch: blockIdx.z = frame; strides in elements between consecutive frames
-    size_t in_fs, out_fs, res_fs, box_fs, dir_fs; // floats
-    size_t pre_fs, stat_fs;                        // doubles
-    size_t aff_fs;                                 // floats between frames of pre_scale / pre_shift (0: shared)
-    unsigned long long* dbg_buf;                   // diagnostic builds only (PP_WINO_STAMP): stamp sums
-    int nb;                                        // frames (persistent kernels loop over them; others use grid.z)
-    // sparse BEV input of the first conv: pillar-index map [Hin*Win] (-1 = empty) + PFN rows [P][64]
-    const int32_t* pmap;
-    const float* feat;
-    size_t pmap_fs, feat_fs;
-    // wino4_mfma: the rectangle of output pixels this launch tiles (a layer whose map is not a multiple of the tile is
-    // covered by a main launch of whole tiles plus strip launches of thin tiles): origin, exclusive end, tiles in x / y
-    int rx0, ry0, rx1, ry1, rnbx, rnby;
-};
+using namespace ppc;
 
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
 struct ConvCfg {
@@ -2114,15 +2021,29 @@ __global__ void __launch_bounds__(512, 2) wino_res(const ConvP p)
 // PREC (the reference's deployed path is TensorRT FP16, framework/trt_utils.py:30): 0 = fp32 MFMA (exact);
 // 1 = split-bf16 "bf16x3": x = hi + lo with hi = bf16(x), lo = bf16(x - hi), a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
 // v_mfma_f32_16x16x16_bf16 with fp32 accumulation (~2^-16 relative per product: fp32-equivalent for this network, three MFMAs at
-// 8x the fp32-MFMA rate); 2 = plain bf16 operands (one MFMA, ~2^-8 per product: the reduced-precision deploy mode).
+// 8x the fp32-MFMA rate); 2 = plain bf16 operands (one MFMA, ~2^-8 per product); 3 = fp16 operands on v_mfma_f32_16x16x16_f16
+// (~2^-11 per product: the arithmetic of the reference's TensorRT FP16 engines).
 // Activations stay fp32 in HBM: normalise + ReLU in fp32, then split / round while staging.  The weight slab in LDS is
 // [K/16][hi|lo][k-group 0..3][BMP rows][4 bf16] -- the same bytes as the fp32 slab.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) // v_cvt_pk_bf16_f32 (round to nearest even)
 {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ unsigned pk_f16(float a, float b) // round to nearest even (v_cvt_pk_f16_f32 on gfx950)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+}
+// one 16-deep MFMA of the reduced-precision 1x1 path: bf16 operands (PREC 1, 2) or fp16 operands (PREC 3), fp32 accumulate
+template <int PREC>
+__device__ __forceinline__ f32x4 mfma_lp(const s16x4 a, const s16x4 b, const f32x4 c)
+{
+    if constexpr (PREC == 3) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
 template <int MT, int NT, int EPI, int PREC = 0>
@@ -2326,7 +2247,8 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
             float v_[4];                                                                         \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) v_[t] = (p.pre != PRE_RAW) ? fmaxf(fmaf(Q[t][j], sc4[t], sh4[t]), 0.f) : Q[t][j]; \
-            const unsigned h0 = pk_bf16(v_[0], v_[1]), h1 = pk_bf16(v_[2], v_[3]);               \
+            const unsigned h0 = (PREC == 3) ? pk_f16(v_[0], v_[1]) : pk_bf16(v_[0], v_[1]);      \
+            const unsigned h1 = (PREC == 3) ? pk_f16(v_[2], v_[3]) : pk_bf16(v_[2], v_[3]);      \
             bh[j] = __builtin_bit_cast(s16x4, (uint2){h0, h1});                                  \
             if constexpr (PREC == 1) {                                                           \
                 const float l0 = v_[0] - __uint_as_float(h0 << 16), l1 = v_[1] - __uint_as_float(h0 & 0xFFFF0000u); \
@@ -2339,10 +2261,10 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             s16x4 al = ah;                                                                       \
             if constexpr (PREC == 1) al = __builtin_bit_cast(s16x4, wl2[(((KB) * 2 + 1) * 4 + kq) * BMP + i * 16 + m]); \
             _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = mfma_lp<PREC>(ah, bh[j], acc[i][j]);                                 \
                 if constexpr (PREC == 1) {                                                       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = mfma_lp<PREC>(ah, bl[j], acc[i][j]);                             \
+                    acc[i][j] = mfma_lp<PREC>(al, bh[j], acc[i][j]);                             \
                 }                                                                                \
             }                                                                                    \
         }                                                                                        \
@@ -2544,16 +2466,6 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // host side: network description, weight packing, launch plans
 // ------------------------------------------------------------------------------------------
-struct Variant { // one compiled tiling of conv_mfma
-    void (*kern)(const ConvP);
-    int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
-    size_t lds;
-    char name[48];
-    int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
-    int cin = 0;  // wino == 2: compiled for exactly this Cin
-    int prec = 0; // wino == 3: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16
-};
-
 template <int KS, int STRIDE, int TW, int WM, int WN, int MT, int NT, int BTX, int KC, int EPI>
 Variant make_variant()
 {
@@ -2703,10 +2615,16 @@ void lp_menu(int kind, int up, std::vector<Variant>& menu)
 void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true, int prec = 0)
 {
     const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
-    // reduced-precision mode (pp_set_precision): the 1x1 contractions -- the three ConvTranspose(k = s) upsamplers and the
-    // 9-anchor head -- run ONLY their bf16x3 / bf16 tilings; the 3x3 convolutions stay on the fp32 MFMA kernels
+    // reduced-precision modes (pp_set_precision): the 1x1 contractions -- the three ConvTranspose(k = s) upsamplers and the
+    // 9-anchor head -- run their bf16x3 / bf16 / fp16 gemm1x1 tilings, the 3x3 convolutions the 16-bit operand kernels of
+    // conv16.hip.  A layer whose shape none of them takes (autotune_layer checks variant_ok / shape_ok) falls back to the
+    // fp32 menu below, and pp_layer_tilings shows it.
     if (prec && g1ok && (kind == 1 || (kind == 2 && head9))) {
-        if (prec == 1) lp_menu<1>(kind, up, menu); else lp_menu<2>(kind, up, menu);
+        if (prec == 1) lp_menu<1>(kind, up, menu); else if (prec == 2) lp_menu<2>(kind, up, menu); else lp_menu<3>(kind, up, menu);
+        return;
+    }
+    if (prec && kind == 0 && cin % 16 == 0) {
+        conv16_menu(stride, prec, menu);
         return;
     }
     if (kind == 2) {
@@ -2764,10 +2682,11 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
     return cost;
 }
 
-bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
+bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4 || v.wino == 5) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
 // shape limits of a tiling family: wino4_mfma stores float2 rows (even output width); gemm1x1 feeds four N-tiles from one
 // dwordx4 of 4 consecutive pixels of the input plane (pixel count a multiple of 4 -- a 9 x 11 map has 99)
-bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)); }
+// conv16 fetches its patches as aligned pixel quads and stores pixel quads (input and output width multiples of 4)
+bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -2882,6 +2801,33 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
         rowsW.swap(perm);
     }
+    if (v.wino == 5) { // conv16: [row block][cin/16][image: hi (| lo for bf16x3)][tap][k-half][BM rows][8 x 16 bit] = the LDS image of a step
+        auto bf16 = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+        auto bf16f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto f16 = [](float f) -> uint16_t { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }; // round to nearest even
+        const int nimg = (v.prec == 1) ? 2 : 1, nblk = rows / v.bm, nch = L.cin / 16;
+        std::vector<uint16_t> pk((size_t)nblk * nch * nimg * 9 * 2 * v.bm * 8, 0);
+        for (int b = 0; b < nblk; ++b)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int t = 0; t < 9; ++t)
+                    for (int h = 0; h < 2; ++h)
+                        for (int mm = 0; mm < v.bm; ++mm)
+                            for (int j = 0; j < 8; ++j) {
+                                const float w = rowsW[((size_t)(b * v.bm + mm) * L.cin + ch * 16 + h * 8 + j) * 9 + t];
+                                const size_t o = (((size_t)(t * 2 + h)) * v.bm + mm) * 8 + j;
+                                const size_t img0 = (((size_t)b * nch + ch) * nimg) * (size_t)(9 * 2 * v.bm * 8);
+                                if (v.prec == 3) pk[img0 + o] = f16(w);
+                                else {
+                                    const uint16_t hi = bf16(w);
+                                    pk[img0 + o] = hi;
+                                    if (nimg == 2) pk[img0 + (size_t)(9 * 2 * v.bm * 8) + o] = bf16(w - bf16f(hi));
+                                }
+                            }
+        if (L.w) (void)hipFree(L.w);
+        PP_HIP(hipMalloc((void**)&L.w, pk.size() * sizeof(uint16_t)));
+        PP_HIP(hipMemcpy(L.w, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        return 0;
+    }
     if (v.wino == 3 && v.prec) { // [row block][K/16][hi|lo][k-group][BMP][4 bf16]: the byte count of the fp32 slab
         auto bf16 = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
         auto bf16f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
@@ -2895,7 +2841,9 @@ int pack_layer(pp_ctx* ctx, Layer& L)
                         if (row >= rows) continue;
                         for (int t = 0; t < 4; ++t) {
                             const float w = rowsW[(size_t)row * L.cin + kb * 16 + q * 4 + t];
-                            const uint16_t hi = bf16(w), lo = bf16(w - bf16f(hi));
+                            uint16_t hi = bf16(w);
+                            if (v.prec == 3) { const _Float16 h16 = (_Float16)w; memcpy(&hi, &h16, 2); } // fp16 operands: the hi image alone is used
+                            const uint16_t lo = bf16(w - bf16f(hi));
                             pk4[(((((size_t)b * nkb + kb) * 2 + 0) * 4 + q) * v.bmp + mm) * 4 + t] = hi;
                             pk4[(((((size_t)b * nkb + kb) * 2 + 1) * 4 + q) * v.bmp + mm) * 4 + t] = lo;
                         }
@@ -3030,6 +2978,17 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         if (g < ncb) g = ncb;
         grid = dim3(g, 1, 1);
     }
+    if (v.wino == 5) { // conv16: persistent, one 4-wave workgroup per CU, XCD-contiguous item ranges (grid a multiple of 8)
+        if ((size_t)L.rows * Hout * Wout * 4 >= 0x80000000ull || (size_t)L.cin * Hin * Win * 4 >= 0x80000000ull) return PP_E_ARG; // buffer offsets are 32-bit, idle lanes park 2 GB out
+        if (p.pre == PRE_STATS) return pp_fail(ctx, PP_E_STATE, "conv16: the producer's statistics must be finalised to (scale, shift)");
+        if ((Win & 3) || (Wout & 3) || (L.cin & 15) || (L.rows % v.bm)) return PP_E_ARG;
+        const int total = pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph) * (L.rows / v.bm) * B;
+        int g = net->num_cu * (v.waves / 4); // workgroups per CU the variant is built for
+
+        if (g > total) g = total;
+        g = (g + 7) & ~7;
+        grid = dim3(g, 1, 1);
+    }
     if (v.wino == 4) {
         // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs.
         // Whole main tiles first; what they leave uncovered goes to strip launches of thin tiles when that needs fewer tiles
@@ -3110,7 +3069,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         ctx->prof_flops = 2.0 * Hout * Wout * (double)L.cin * L.cout * 9.0 * B;
         PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used], stream));
     }
-    hipLaunchKernelGGL(v.kern, grid, dim3(v.threads), lds_bytes, stream, p);
+    hipLaunchKernelGGL((pmap && v.kern2) ? v.kern2 : v.kern, grid, dim3(v.threads), lds_bytes, stream, p);
     if (tag) {
         PP_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], stream));
         ctx->prof_used += 2;
@@ -3189,12 +3148,33 @@ void tune_cache_save()
 constexpr int TUNE_FRAMES = 16;         // frames per timed launch of the tuner (half the default bench pass of 32; the picks do not change beyond 16)
 constexpr size_t TUNE_OUT_FS = 0, TUNE_IN_FS = 0; // 0: natural per-frame strides
 
-int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose)
+int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose, bool measure = true)
 {
     pp_net* net = (pp_net*)ctx->net;
     char sig[160];
     std::vector<Variant> menu;
+    const int rows_ = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
+    auto legal = [&](const Variant& v) {
+        return variant_ok(v, rows_) && shape_ok(v, Hin, Win, Wout) && ((v.wino == 3) ? g1_lds(v, L.cin) : v.lds) <= (size_t)160 * 1024;
+    };
     layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, ctx->precision);
+    if (ctx->precision) {
+        // a shape none of the reduced-precision tilings takes (odd maps, Cin not a multiple of 16 / 32) runs its fp32 tilings:
+        // pp_layer_tilings reports what really runs
+        bool any = false;
+        for (const Variant& v : menu) any = any || legal(v);
+        if (!any) {
+            menu.clear();
+            layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, 0);
+        }
+    }
+    if (!measure) { // no on-device tuning (PP_AUTOTUNE=0 / maps the tuner's buffers do not fit): fp32 keeps pick_variant's choice,
+                    // a reduced-precision mode takes the first legal entry of its menu
+        if (ctx->precision)
+            for (const Variant& v : menu)
+                if (legal(v) && v.prec == ctx->precision) { L.var = v; return 0; }
+        return 0;
+    }
     // the key carries the library version and the menu size (an entry of another build's menu is not trusted), not the
     // device index: the GPUs of a node are identical, and ranks must be able to share rank 0's table
     snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d p%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
@@ -3223,6 +3203,7 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
         const size_t need = (v.wino == 3) ? g1_lds(v, L.cin) : v.lds;
         L.var = v;
         PP_HIP(hipFuncSetAttribute((const void*)v.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+        if (v.kern2) PP_HIP(hipFuncSetAttribute((const void*)v.kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
         int rc = pack_layer(ctx, L);
         if (rc) return rc;
         float ms = 0.f;
@@ -3427,14 +3408,16 @@ int pp_net_commit(pp_ctx* ctx)
         }
         for (Layer& L : net->layers) {
             int rc = 0;
-            if (can_tune) {
+            {
                 const int h = H >> L.level, w = W >> L.level;
                 const int hin = (L.kind == 0 && L.stride == 2) ? h * 2 : h, win = (L.kind == 0 && L.stride == 2) ? w * 2 : w;
-                rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose);
-                if (rc) { (void)hipFree(tin); (void)hipFree(tout); return rc; }
+                if (!can_tune && ctx->precision == 0) L.var = pick_variant(L.kind, L.stride, L.up, (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout), h, w, ctx->cfg.num_anchor_per_loc == 9);
+                rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose, can_tune);
+                if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
             }
             PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(L.var.wino == 3 ? g1_lds(L.var, L.cin) : L.var.lds)));
+            if (L.var.kern2) PP_HIP(hipFuncSetAttribute((const void*)L.var.kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
             rc = pack_layer(ctx, L);
             if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
         }
@@ -3698,13 +3681,14 @@ extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
 }
 
 // Executed MFMA flops / algorithmic (direct-convolution) flops of the dominant layer's tiling: Winograd F(2x2,3x3)
-// issues 16 multiplications per 2x2 output tile where the direct form needs 36.
+// issues 16 multiplications per 2x2 output tile where the direct form needs 36; split-bf16 issues three MFMAs per product.
 extern "C" double pp_dominant_executed_ratio(pp_ctx* ctx)
 {
     if (!ctx || !ctx->net) return 1.0;
     pp_net* net = (pp_net*)ctx->net;
     for (const Layer& L : net->layers)
-        if (L.kind == 0 && L.level == 0 && L.stride == 1) return (L.var.wino == 1 || L.var.wino == 2 || L.var.wino == 4) ? 4.0 / 9.0 : 1.0;
+        if (L.kind == 0 && L.level == 0 && L.stride == 1)
+            return (L.var.wino == 1 || L.var.wino == 2 || L.var.wino == 4) ? 4.0 / 9.0 : (L.var.wino == 5 && L.var.prec == 1) ? 3.0 : 1.0; // bf16x3: three MFMAs per product
     return 1.0;
 }
 

@@ -98,7 +98,7 @@ struct pp_ctx {
     float* pfn_scale = nullptr; // [64]
     float* pfn_shift = nullptr; // [64]
     void* net = nullptr;        // opaque pp_net (conv.hip)
-    int precision = 0;          // pp_set_precision: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 bf16 -- for the 1x1 contractions
+    int precision = 0;          // pp_set_precision: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 bf16, 3 fp16 operands -- convs, upsamplers and head
     // ---- measurement (pp_profile_begin/end) ----
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; // start/stop pairs

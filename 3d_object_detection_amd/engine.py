@@ -139,7 +139,7 @@ def _stream():
 class Engine:
     """Owns a pp_ctx.  Created lazily through engine_for(config)."""
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 
     def __init__(self, config, device_index=0, norm="instance", max_points=None, max_batch=None, precision="fp32"):
         self.lib = _lib.load()

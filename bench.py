@@ -38,6 +38,7 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+LP_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 MFMA dense peak (reduced-precision deploy modes, tagged lines only)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 CLOUD_DESC = {"eight_20cm": "KITTI-shape 64-beam 20k-point", "ntusl_10cm": "64-beam two-sweep 60k-point", "nuscene": "nuScenes-shape 32-beam 34k-point"}
 
@@ -123,9 +124,19 @@ def cpu_baseline(synth, config, n_frames=8):
             "sample": f"{n_frames} frames of {config} ({clouds[0].shape[0]}-pt clouds, batch=1) after 1 warm-up, oracle/ CPU path, {dt:.1f} s"}
 
 
+def executed_factor(L):
+    """Executed / algorithmic MFMA flops of a layer's tiling: Winograd F(2x2,3x3) executes 4/9; a split-bf16 ("bf16x3", p1)
+    tiling issues three bf16 MFMAs per product."""
+    if L["wino"] in (1, 2, 4):
+        return 4.0 / 9.0
+    if " p1" in L["tiling"]:
+        return 3.0
+    return 1.0
+
+
 def frame_flops(H, W, tilings):
     """Algorithmic (direct-convolution) and executed MFMA flops of one frame from the launch plan (SURVEY 8(d) formula:
-    203.2 GFLOP at eight_20cm).  A Winograd F(2x2,3x3) layer executes 4/9 of its algorithmic multiplications."""
+    203.2 GFLOP at eight_20cm)."""
     alg = ex = 0.0
     for L in tilings:
         hw = (H >> L["level"]) * (W >> L["level"])
@@ -136,11 +147,11 @@ def frame_flops(H, W, tilings):
         else:
             f = 2.0 * hw * L["cin"] * L["cout"]
         alg += f
-        ex += f * (4.0 / 9.0 if L["wino"] in (1, 2, 4) else 1.0)
+        ex += f * executed_factor(L)
     return alg, ex
 
 
-def stage_rooflines(eng, clouds, NB, cfg, passes=3):
+def stage_rooflines(eng, clouds, NB, cfg, passes=3, mfma_peak=F32_MFMA_PEAK_TFLOPS):
     """Untimed side pass with one HIP event per stage boundary (pp_stage_profile_*): GPU ms per stage and frame, against
     the algorithmic HBM bytes of SURVEY 8(d) (fp32) and the 8 TB/s peak; conv / head stages against the MFMA peak."""
     eng.infer_batch(clouds[:NB])
@@ -173,17 +184,18 @@ def stage_rooflines(eng, clouds, NB, cfg, passes=3):
     alg, ex = frame_flops(eng.H, eng.W, til)
     head = [L for L in til if L["kind"] == 2]
     alg_h, _ = frame_flops(eng.H, eng.W, head)
-    for k, (a_, e_) in {"conv": (alg - alg_h, ex - alg_h), "head": (alg_h, alg_h)}.items():
+    _, ex_h = frame_flops(eng.H, eng.W, head)
+    for k, (a_, e_) in {"conv": (alg - alg_h, ex - ex_h), "head": (alg_h, ex_h)}.items():
         t = per_frame[k] * 1e-3
         out[k] = {"bound": "mfma", "ms_per_frame": round(per_frame[k], 5), "algorithmic_flops_per_frame": a_, "executed_flops_per_frame": e_,
-                  "achieved": round(e_ / t / 1e12, 2) if t > 0 else 0.0, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(e_ / t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if t > 0 else 0.0}
+                  "achieved": round(e_ / t / 1e12, 2) if t > 0 else 0.0, "peak": mfma_peak, "unit": "TFLOP/s",
+                  "frac": round(e_ / t / 1e12 / mfma_peak, 4) if t > 0 else 0.0}
     parts = ("post_filter", "post_topk_decode", "post_nms")
     out["postprocess"]["parts_ms_per_frame"] = {k: round(per_frame[k], 5) for k in parts}
     total = sum(v for k, v in per_frame.items() if k not in parts)
     whole = {"gpu_ms_per_frame": round(total, 5), "algorithmic_gflop": round(alg / 1e9, 2), "executed_gflop": round(ex / 1e9, 2),
              "executed_tflops": round(ex / (total * 1e-3) / 1e12, 2) if total > 0 else 0.0,
-             "executed_frac": round(ex / (total * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if total > 0 else 0.0,
+             "executed_frac": round(ex / (total * 1e-3) / 1e12 / mfma_peak, 4) if total > 0 else 0.0,
              "mean_points": N, "mean_pillars": P}
     return out, whole, til
 
@@ -199,8 +211,8 @@ def main():
                     help="independent frames per pass per GPU (pp_infer_batch: frame = grid.z of the conv launches); weak scaling")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="TOTAL frames per step, sharded by frame index over the ranks (strong scaling; BASELINE config 5: 64)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the 1x1 contractions (pp_set_precision); anything but fp32 prints a TAGGED line, never the headline")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
+                    help="MFMA operand type of convolutions, upsamplers and head (pp_set_precision); anything but fp32 prints a TAGGED line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (stage rooflines, batch-1 latency, trained-like bias)")
@@ -373,25 +385,48 @@ def main():
         }
         ach = (k_flops / (k_ms * 1e-3) / 1e12) if k_ms > 0 else 0.0
         traffic, traffic_src = hbm_traffic(eng.dominant_kernel(), min(NB, MAXB), eng.H, eng.W)
-        out["roofline"] = {"bound": "mfma", "kernel": f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{min(NB, MAXB)} frames, tiling '{eng.dominant_kernel()}'",
-                           "achieved": round(ach * ratio, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach * ratio / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_launch_ms": round(k_ms, 5), "launches": k_n,
-                           "algorithmic_flops_per_launch": k_flops, "executed_flops_per_launch": k_flops * ratio,
-                           "algorithmic_tflops": round(ach, 3),
-                           "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
-                                   "count in `algorithmic_*`)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+        kname = f"conv 3x3 s1 64->64 @ {eng.H}x{eng.W} x{min(NB, MAXB)} frames, tiling '{eng.dominant_kernel()}'"
+        if args.precision == "fp32":
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": round(ach * ratio, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach * ratio / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                               "algorithmic_flops_per_launch": k_flops, "executed_flops_per_launch": k_flops * ratio,
+                               "algorithmic_tflops": round(ach, 3),
+                               "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
+                                       "count in `algorithmic_*`)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+        else:
+            # 16-bit operands: the same layer is no longer bound by the matrix pipe.  Both floors are stated, the binding one
+            # (the larger time) is the roofline: HBM with SURVEY 8(d)'s algorithmic bytes (input read once + output written
+            # once, fp32 activations: 2 * 4 * 64 * H * W per frame), MFMA with the executed flops at the 16-bit dense peak.
+            nfr = min(NB, MAXB)
+            alg_bytes = 2.0 * 4 * 64 * eng.H * eng.W * nfr
+            t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+            t_mfma = k_flops * ratio / (LP_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+            hbm_bound = t_hbm >= t_mfma
+            gbs = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                               "achieved": round(gbs, 1) if hbm_bound else round(ach * ratio, 2),
+                               "peak": HBM_PEAK_GBS if hbm_bound else LP_MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                               "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (ach * ratio / LP_MFMA_PEAK_TFLOPS), 4),
+                               "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                               "algorithmic_bytes_per_launch": alg_bytes, "executed_flops_per_launch": k_flops * ratio,
+                               "floors_ms": {"hbm_8TBps": round(t_hbm, 5), "mfma_16bit_2500TF": round(t_mfma, 5)},
+                               "mfma_frac": round(ach * ratio / LP_MFMA_PEAK_TFLOPS, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "note": "16-bit operand mode: floors of this layer per launch in `floors_ms`; the larger one is the bound"}
         if args.precision != "fp32":
-            out["tagged"] = (f"reduced-precision deploy mode '{args.precision}' of the 1x1 contractions (upsamplers + head; SURVEY 8(f).4): NOT the headline -- "
+            out["tagged"] = (f"reduced-precision deploy mode '{args.precision}': convolutions, upsamplers and head on 16-bit MFMA operands, fp32 accumulation, "
+                             "fp32 activations in HBM (SURVEY 8(f).4; the reference deploys TensorRT FP16 engines): NOT the headline -- "
                              "the headline is the fp32 line (dtype f32); tolerance table in DESIGN.md")
         if stub or (world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl"):
             out["rehearsal"] = "stub engine / ranks share devices, gather over gloo: not a measurement"
         if world == 1 and not args.no_extras and not stub:
-            stages, whole, til = stage_rooflines(eng, clouds, min(NB, MAXB), cfg)
+            stages, whole, til = stage_rooflines(eng, clouds, min(NB, MAXB), cfg, mfma_peak=F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else LP_MFMA_PEAK_TFLOPS)
             out["roofline"]["stages"] = stages
             out["roofline"]["whole_frame"] = whole
             out["extras"] = extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D)
             out["extras"]["tilings"] = [L["tiling"] for L in til]
+            out["roofline"]["batch1"] = out["extras"].pop("batch1_roofline")
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(synth, args.config, args.cpu_frames)
         print(json.dumps(out), flush=True)
@@ -406,7 +441,7 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
     # after every frame like train.py:236 -- resident cloud, and from pinned host memory
     # -- with an engine of its own (max_batch = 1: the tuner then measures the tilings at ONE frame per launch, where smaller
     # tiles win), as a batch-1 deployment would be built; `..._batch_engine` is the same through the 32-frame engine's tilings
-    eng1 = eng_mod.Engine(dict(cfg), device_index=local, max_batch=1)
+    eng1 = eng_mod.Engine(dict(cfg), device_index=local, max_batch=1, precision=args.precision)
     eng1.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
     n = 30
     for tag, e in (("", eng1), ("_batch_engine", eng)):
@@ -426,7 +461,16 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
             dt = time.perf_counter() - t0
             out[f"batch1_latency_ms_{name}{tag}"] = round(dt / n * 1e3, 4)
             out[f"batch1_frames_per_s_{name}{tag}"] = round(n / dt, 2)
-    out["batch1_tilings"] = [L["tiling"] for L in eng1.layer_tilings()]
+    til1 = eng1.layer_tilings()
+    out["batch1_tilings"] = [L["tiling"] for L in til1]
+    # BASELINE config 2 (batch = 1) with its own roofline: executed MFMA flops of ONE frame over the whole synchronised call
+    alg1, ex1 = frame_flops(eng1.H, eng1.W, til1)
+    peak1 = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else LP_MFMA_PEAK_TFLOPS
+    ms1 = out["batch1_latency_ms_resident"]
+    out["batch1_roofline"] = {"bound": "mfma", "ms_per_frame": ms1, "algorithmic_gflop": round(alg1 / 1e9, 2), "executed_gflop": round(ex1 / 1e9, 2),
+                              "achieved": round(ex1 / (ms1 * 1e-3) / 1e12, 2), "peak": peak1, "unit": "TFLOP/s",
+                              "frac": round(ex1 / (ms1 * 1e-3) / 1e12 / peak1, 4),
+                              "note": "one pp_infer_frame per frame, host-synchronised after every frame (train.py:236); wall time incl. launch gaps"}
     del eng1
     # the same resident pass with a trained-like head bias (few candidates instead of ~900 detections per frame)
     if args.cls_bias is None:

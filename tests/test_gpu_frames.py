@@ -277,36 +277,90 @@ def test_nuscene_10class_head(synth):
     compare_frame(r1, gpu_logits(eng, 0), d1[:c1[0]].cpu().numpy(), c1, 1, "fused nuscene 10-class rotated NMS")
 
 
+# tolerance table of the reduced-precision deploy modes: max |logit - fp32 path's logit| and the share of the
+# fp32 path's detections that must be reproduced within 0.1 m / 0.05 score
+PRECISION_BARS = {"bf16x3": (1e-3, None), "fp16": (0.03, 0.95), "bf16": (0.15, 0.85)}
+
+
+def _reproduced(ref_rows, rows):
+    n = 0
+    for row in ref_rows:
+        d = np.abs(rows[:, :3] - row[:3]).max(axis=1) + (rows[:, 8] != row[8]) * 1e3 + np.abs(rows[:, 7] - row[7]) * 2
+        n += bool(d.size and d.min() <= 0.1)
+    return n
+
+
 def test_reduced_precision_modes(synth):
-    """pp_set_precision -- the 1x1 contractions (three upsamplers + head) as split-bf16 ("bf16x3", fp32-equivalent)
-    or plain bf16 MFMAs.  bf16x3 must still meet the fp32 parity bar against the oracle; bf16 gets its own tolerance (printed,
-    DESIGN.md table): logits within 0.1 of the fp32 path, >= 90 % of the fp32 path's detections reproduced within 0.1 m / 0.05 score."""
+    """pp_set_precision -- the WHOLE network behind the PFN on 16-bit MFMA operands with fp32 accumulation and fp32
+    activations in HBM: the 3x3 convolutions (stride 1 and 2, conv16.hip), the three upsamplers and the head (gemm1x1), as
+    split-bf16 ("bf16x3", fp32-equivalent), fp16 (the arithmetic of the reference's TensorRT FP16 engines, trt_utils.py:30) or
+    bf16.  bf16x3 must still meet the fp32 parity bar against the oracle (compare_frame at 1e-3, every detection matched by
+    anchor id); fp16 and bf16 get their own stated bars (PRECISION_BARS; printed)."""
     eng_mod = load_pkg("engine")
     sd = synth.seeded_state_dict(1, cls_bias=-3.0)
     pts = synth.lidar_cloud("nuscene", seed=77)
     cloud = torch.from_numpy(pts).cuda()
     r = oracle_frame(synth, "nuscene", pts, sd)
     out = {}
-    for mode in ("fp32", "bf16x3", "bf16"):
+    for mode in ("fp32", "bf16x3", "fp16", "bf16"):
         eng = eng_mod.Engine(make_cfg(synth, "nuscene"), precision=mode)
         eng.load_state_dict(sd)
-        til = [t["tiling"] for t in eng.layer_tilings() if t["kind"] != 0]
-        assert all((" p1" in t) if mode == "bf16x3" else (" p2" in t) if mode == "bf16" else (" p" not in t) for t in til), til
+        til = eng.layer_tilings()
+        code = eng.PRECISIONS[mode]
+        for t in til:  # what really runs: every conv on conv16, every 1x1 contraction on the reduced-precision gemm1x1
+            name = t["tiling"]
+            if mode == "fp32":
+                assert not name.startswith("c16") and " p" not in name, name
+            elif t["kind"] == 0:
+                assert name.startswith(f"c16 s{t['stride']} p{code} "), name
+            else:
+                assert name.endswith(f" p{code}"), name
         det, cnt = eng.infer_frame(cloud)
         cnt = cnt.cpu().numpy()
         gl = gpu_logits(eng, 0)
         out[mode] = (gl, det[:cnt[0]].cpu().numpy(), cnt)
-        if mode != "bf16":
+        if mode in ("fp32", "bf16x3"):
             compare_frame(r, gl, out[mode][1], cnt, 0, f"nuscene precision {mode}")
-    f32, b16 = out["fp32"], out["bf16"]
-    dev = {k: float(np.abs(b16[0][k] - f32[0][k]).max()) for k in ("cls", "box", "dir")}
-    dev3 = {k: float(np.abs(out["bf16x3"][0][k] - f32[0][k]).max()) for k in ("cls", "box", "dir")}
-    matched = 0
-    for row in f32[1]:
-        d = np.abs(b16[1][:, :3] - row[:3]).max(axis=1) + (b16[1][:, 8] != row[8]) * 1e3 + np.abs(b16[1][:, 7] - row[7]) * 2
-        matched += bool(d.size and d.min() <= 0.1)
-    frac = matched / max(f32[1].shape[0], 1)
-    print(f"[precision] logit deviation from the fp32 path: bf16x3 {dev3}, bf16 {dev}; bf16 reproduces {matched}/{f32[1].shape[0]} fp32 detections "
-          f"({frac:.3f}) within 0.1 m / 0.05 score, {b16[1].shape[0]} detections in all")
-    assert max(dev3.values()) <= 1e-4
-    assert max(dev.values()) <= 0.1 and frac >= 0.9
+    f32 = out["fp32"]
+    for mode, (bar, share) in PRECISION_BARS.items():
+        dev = {k: float(np.abs(out[mode][0][k] - f32[0][k]).max()) for k in ("cls", "box", "dir")}
+        hit = _reproduced(f32[1], out[mode][1])
+        frac = hit / max(f32[1].shape[0], 1)
+        line = (f"[precision] {mode}: logit deviation from the fp32 path cls {dev['cls']:.2e} box {dev['box']:.2e} dir {dev['dir']:.2e} (bar {bar:g}); "
+                f"{hit}/{f32[1].shape[0]} fp32 detections reproduced within 0.1 m / 0.05 score ({frac:.3f}), {out[mode][1].shape[0]} detections in all")
+        print(line)
+        report(line)
+        assert max(dev.values()) <= bar, (mode, dev)
+        if share is not None:
+            assert frac >= share, (mode, frac)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16"])
+def test_reduced_precision_bench_path(mode, synth, eight_ref):
+    """The 16-bit operand kernels on the workload bench.py times (eight_20cm, pp_infer_batch, sparse first conv through conv16's
+    twin kernel, 400 / 200 / 100 maps): bf16x3 against the oracle at the fp32 bar; fp16 against the oracle's logits at its own bar
+    and with the GPU's selection exact on its own logits (compare_frame steps 1-3 hold for every mode)."""
+    pts, refs = eight_ref
+    sd, r = refs["rand"]
+    eng_mod = load_pkg("engine")
+    eng = eng_mod.Engine(make_cfg(synth, "eight_20cm"), max_batch=3, precision=mode)
+    eng.load_state_dict(sd)
+    assert all(t["tiling"].startswith("c16") for t in eng.layer_tilings() if t["kind"] == 0)
+    clouds = [torch.from_numpy(synth.lidar_cloud("eight_20cm", seed=31)).cuda(), torch.from_numpy(pts).cuda(),
+              torch.zeros((0, 4), dtype=torch.float32).cuda()]
+    det_b, cnt_b = eng.infer_batch(clouds)
+    cnt = cnt_b[1].cpu().numpy()
+    det = det_b[1, :cnt[0]].cpu().numpy()
+    gl = gpu_logits(eng, 1)
+    if mode == "bf16x3":
+        compare_frame(r, gl, det, cnt, "aabb", f"batched sparse eight_20cm {mode}")
+    else:
+        dev = max(float(np.abs(gl[k] - r[k]).max()) for k in ("cls", "box", "dir"))
+        det_self, counts_self = O.postprocess(gl["cls"], gl["box"], gl["dir"], r["mask"], r["anchors"], r["class_masks"], r["center_limit"], nms_fn=C.nms_aabb)
+        line = f"[precision] batched sparse eight_20cm {mode}: max logit deviation from the oracle {dev:.2e} (bar {PRECISION_BARS[mode][0]:g}), {det.shape[0]} detections = the oracle's post-processing of the GPU's own logits"
+        print(line)
+        report(line)
+        assert dev <= PRECISION_BARS[mode][0]
+        assert list(cnt[1:4]) == counts_self and det.shape == det_self.shape
+        np.testing.assert_allclose(det, det_self, rtol=2e-5, atol=2e-5)
+    assert int(cnt_b[2, 0]) == 0
