@@ -210,8 +210,8 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def set_precision(self, mode):
-        """Arithmetic of the 1x1 contractions (upsamplers + head): "fp32" (exact, default), "bf16x3" (split-bf16, fp32-equivalent),
-        "bf16" (reduced-precision deploy mode).  Re-commits the loaded weights for the new tilings."""
+        """MFMA operand type of the convolutions, upsamplers and head: "fp32" (exact, default), "bf16x3" (split-bf16, fp32-equivalent),
+        "fp16" / "bf16" (reduced-precision deploy modes).  Re-commits the loaded weights for the new tilings."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _lib.check(self.lib.pp_set_precision(self.ctx, self.PRECISIONS[mode]), self.ctx, "pp_set_precision")

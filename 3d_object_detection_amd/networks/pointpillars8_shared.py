@@ -32,10 +32,10 @@ class PointPillars:
 
     def half(self):
         """The reference deploys FP16 TensorRT engines (framework/trt_utils.py:30, networks/pointpillars8_trt.py:208-223,295-314).
-        Here: the reduced-precision deploy mode of the 1x1 contractions (upsamplers + head) on the bf16 MFMAs, activations
-        still fp32 in HBM and the 3x3 convolutions on the fp32 kernels; tolerance table in DESIGN.md.  The parity contract
-        (<= 1e-3 vs the fp32 reference) is stated for float() / the default."""
-        self._eng.set_precision("bf16")
+        Here: fp16 MFMA operands for every convolution, upsampler and the head, fp32 accumulation, activations still fp32 in
+        HBM; tolerance table in DESIGN.md.  The parity contract (<= 1e-3 vs the fp32 reference) is stated for float() / the
+        default (and is also met by precision("bf16x3"))."""
+        self._eng.set_precision("fp16")
         return self
 
     def float(self):
@@ -43,7 +43,7 @@ class PointPillars:
         return self
 
     def precision(self, mode):
-        """ "fp32" | "bf16x3" (split-bf16: fp32-equivalent on the bf16 MFMAs) | "bf16"."""
+        """ "fp32" | "bf16x3" (split-bf16: fp32-equivalent on the bf16 MFMAs) | "fp16" | "bf16"."""
         self._eng.set_precision(mode)
         return self
 

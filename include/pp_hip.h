@@ -64,12 +64,17 @@ const char* pp_last_error(pp_ctx* ctx); /* ctx may be NULL: last pp_create failu
 int pp_load_weights(pp_ctx* ctx, const char* name, const void* host_ptr_h, const int64_t* shape_h, int ndim);
 int pp_commit_weights(pp_ctx* ctx);
 
-/* Arithmetic of the 1x1 contractions (the three ConvTranspose(k = s) upsamplers and the head), SURVEY 8(f).4 -- the reference's
- * deployed path is TensorRT FP16 (framework/trt_utils.py:30, networks/pointpillars8_trt.py:208-223,295-314):
- * 0 fp32 MFMA (default, exact, the parity path); 1 split-bf16 "bf16x3" on the bf16 MFMAs with fp32 accumulation (fp32-equivalent
- * for this network); 2 plain bf16 operands (reduced-precision deploy mode, own tolerance table).  Activations stay
- * fp32 in HBM and the 3x3 convolutions stay on the fp32 kernels in every mode.  Call before pp_commit_weights (a change of mode
- * invalidates the committed weights until the next commit). */
+/* MFMA operand type of the network behind the PFN -- every 3x3 convolution (stride 1 and 2), the three ConvTranspose(k = s)
+ * upsamplers and the head -- SURVEY 8(f).4; the reference's deployed path is TensorRT FP16 (framework/trt_utils.py:30,
+ * networks/pointpillars8_trt.py:208-223,295-314):
+ *   0 fp32 MFMA (default, exact, the parity path);
+ *   1 split-bf16 "bf16x3" (x = hi + lo, three bf16 MFMAs per product, fp32 accumulation: fp32-equivalent for this network,
+ *     meets the fp32 parity bar -- DESIGN.md);
+ *   2 bf16 operands;   3 fp16 operands (the reference's deploy arithmetic) -- own tolerance table in DESIGN.md.
+ * Accumulation is fp32 and activations stay fp32 NCHW in HBM in every mode (normalise + ReLU in fp32, round while staging).
+ * A layer whose shape none of the 16-bit tilings takes (maps not a multiple of 4 wide, Cin not a multiple of 16 / 32) keeps its
+ * fp32 tiling: pp_layer_tilings reports what runs.  Call before pp_commit_weights (a change of mode invalidates the committed
+ * weights until the next commit). */
 int pp_set_precision(pp_ctx* ctx, int mode);
 
 /* Anchor table built by the host mirror of AnchorAssigner.__init__ (anchor_assigner.py:221-298):
