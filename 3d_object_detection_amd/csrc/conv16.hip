@@ -45,6 +45,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 enum { P16_BF16X3 = 1, P16_BF16 = 2, P16_FP16 = 3 };
 
+// diagnostic build (make stamp16; tools/c16_stamp.py): s_memtime sums of the phases of an item, lane 0 of wave 0 of every
+// workgroup, into ConvP::dbg_buf[0..7] = prologue | loads issued | tap loop | barrier after the taps | commit + rest of staging |
+// second barrier | epilogue | items
+#ifndef C16_STAMP
+#define C16_STAMP 0
+#endif
+#if C16_STAMP
+#define C16_T(x) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[x] += t_ - tl_; tl_ = t_; }
+#else
+#define C16_T(x)
+#endif
+
 template <int PREC>
 __device__ __forceinline__ unsigned pack2(float a, float b)
 {
@@ -159,6 +171,10 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
     }
     const int aoff = kh * C::BM + wm * MT * 32 + n32;
 
+#if C16_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = slot; it < per_xcd; it += nslots) {
         const int item = xcd * per_xcd + it;
         if (item >= total) break;
@@ -312,10 +328,12 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
         };
 
         if (any) {
+            C16_T(6)
             issue_all(0);
             commit_all(0, 0);
             if constexpr (!C::DB) stage_rest(0);
             __syncthreads();
+            C16_T(0)
             for (int step = 0; step < nsteps; ++step) {
                 const int buf = C::DB ? (step & 1) : 0;
                 const bool stage = step + 1 < nsteps && !(p.dbg & 1);
@@ -323,6 +341,7 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
                     if constexpr (C::DB) issue_all(step + 1);
                     else { issue_x(step + 1, I0{}, I0{}); load_aff(step + 1); }
                 }
+                C16_T(1)
                 const u32x4* xb = xl + buf * C::X_UNITS;
                 const u32x4* wb = wl + buf * C::W_UNITS;
                 // operand reads run ONE TAP AHEAD of the MFMAs that consume them (two register sets, order pinned with
@@ -350,14 +369,20 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
                         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<PREC>(a[cur][i], b[cur][j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                C16_T(2)
                 if constexpr (C::DB) {
                     if (stage && !(p.dbg & 128)) commit_all(step + 1, buf ^ 1);
+                    C16_T(4)
                     __syncthreads();
+                    C16_T(5)
                 } else {
                     __syncthreads(); // every wave is done reading the operands of this step
+                    C16_T(3)
                     if (stage) {
                         if (!(p.dbg & 128)) { commit_x(step + 1, 0, I0{}, I0{}); stage_rest(step + 1); }
+                        C16_T(4)
                         __syncthreads();
+                        C16_T(5)
                     }
                 }
             }
@@ -456,7 +481,15 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
             }
         }
         if (p.stat_acc || !C::DB) __syncthreads(); // red (and, single-buffered, the transpose tiles inside the operand buffers) are rewritten by the next item
+#if C16_STAMP
+        st_[7] += 1;
+#endif
     }
+#if C16_STAMP
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[6] += t_ - tl_; }
+    if (p.dbg_buf && tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(p.dbg_buf + k, st_[k]);
+#endif
 }
 
 template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC>
