@@ -20,8 +20,9 @@
 //   one lane.  Row stride == PW (mod 16 units): a wave's 32 lanes then read 32 consecutive units modulo 16 -> conflict-free
 //   ds_read_b128 for every tap shift.  Stride 2: even / odd columns de-interleaved (the tile walk stays unit-stride).
 //   The weights of the step, pre-packed on the host in the LDS image [tap][k-half][row][8], are a linear copy.
-// * Double-buffered LDS, one barrier per step: the loads of step s+1 are issued before the 9 * MT * NT MFMAs of step s and
-//   written to the other buffer behind them.
+// * Double-buffered LDS, one barrier per step, ONE staging register set written after the barrier and re-requested at once:
+//   at the top of step s the data of step s+1 (requested a whole step earlier) is written to the other buffer and the
+//   loads of step s+2 are requested right behind it, then the 9 * MT * NT MFMAs of step s run.
 // * bf16x3: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), x * w ~ hi*hi + hi*lo + lo*hi as THREE steps per 16 channels
 //   with the same LDS footprint (the step re-stages the part it needs; the fp32 patch comes from L2 the second and third
 //   time), 3x the MFMAs of bf16 -- fp32-equivalent for this network (DESIGN.md tolerance table).
@@ -332,14 +333,26 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
             issue_all(0);
             commit_all(0, 0);
             if constexpr (!C::DB) stage_rest(0);
+            else if (nsteps > 1 && !(p.dbg & 1)) issue_all(1);
             __syncthreads();
             C16_T(0)
             for (int step = 0; step < nsteps; ++step) {
                 const int buf = C::DB ? (step & 1) : 0;
                 const bool stage = step + 1 < nsteps && !(p.dbg & 1);
                 if (stage) {
-                    if constexpr (C::DB) issue_all(step + 1);
-                    else { issue_x(step + 1, I0{}, I0{}); load_aff(step + 1); }
+                    if constexpr (C::DB) {
+                        // ONE register set, written AFTER the barrier and re-requested at once: the data of step s+1 (requested a
+                        // whole step ago) goes to the other buffer -- free since the barrier that closed step s-1 -- and the
+                        // requests of step s+2 leave right behind it, so loads are in flight during every phase of the step
+                        // (the first version requested at the top of a step and wrote at its end: one burst per step, and the
+                        // memory pipe idle while the wave multiplied and converted)
+                        if (!(p.dbg & 128)) commit_all(step + 1, buf ^ 1);
+                        C16_T(4)
+                        if (step + 2 < nsteps) issue_all(step + 2);
+                    } else {
+                        issue_x(step + 1, I0{}, I0{});
+                        load_aff(step + 1);
+                    }
                 }
                 C16_T(1)
                 const u32x4* xb = xl + buf * C::X_UNITS;
@@ -371,8 +384,6 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
                 });
                 C16_T(2)
                 if constexpr (C::DB) {
-                    if (stage && !(p.dbg & 128)) commit_all(step + 1, buf ^ 1);
-                    C16_T(4)
                     __syncthreads();
                     C16_T(5)
                 } else {
