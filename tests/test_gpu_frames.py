@@ -364,3 +364,43 @@ def test_reduced_precision_bench_path(mode, synth, eight_ref):
         assert list(cnt[1:4]) == counts_self and det.shape == det_self.shape
         np.testing.assert_allclose(det, det_self, rtol=2e-5, atol=2e-5)
     assert int(cnt_b[2, 0]) == 0
+
+
+def test_reduced_precision_batchnorm_and_fallback(synth):
+    """Two corners of the 16-bit modes.  (1) The BatchNorm backbone (pointpillars8_export.py:54-119: folded (scale, shift) per channel,
+    shared by all frames -- ConvP::aff_fs = 0) in bf16x3 against the oracle at the fp32 bar.  (2) A grid whose maps are not multiples
+    of 4 wide (72 x 88 cells -> 36 x 44, 18 x 22, 9 x 11): the 16-bit tilings take only the layers whose input AND output widths are
+    multiples of 4; every other layer must fall back to its fp32 tiling (pp_layer_tilings says which), and the frame must still
+    meet the bar."""
+    eng_mod = load_pkg("engine")
+    # (1)
+    sd = synth.seeded_state_dict(1, norm="batch", cls_bias=-3.0)
+    eng = eng_mod.Engine(make_cfg(synth, "nuscene"), norm="batch", precision="bf16x3")
+    eng.load_state_dict(sd)
+    assert all(t["tiling"].startswith("c16") for t in eng.layer_tilings() if t["kind"] == 0)
+    pts = synth.lidar_cloud("nuscene", seed=77)
+    det, cnt = eng.infer_frame(torch.from_numpy(pts).cuda())
+    cnt = cnt.cpu().numpy()
+    r = oracle_frame(synth, "nuscene", pts, sd, "batch")
+    compare_frame(r, gpu_logits(eng, 0), det[:cnt[0]].cpu().numpy(), cnt, 0, "fused nuscene batch-norm bf16x3")
+    # (2)
+    over = dict(detection_range=[0.0, -8.8, -2.5, 14.4, 8.8, 8.5], max_voxels=4000)
+    sd = synth.seeded_state_dict(6, cls_bias=-3.0)
+    eng = eng_mod.Engine(make_cfg(synth, "eight_20cm", **over), precision="bf16x3")
+    eng.load_state_dict(sd)
+    til = eng.layer_tilings()
+    widths = {0: 44, 1: 22, 2: 11}
+    for t in til:
+        if t["kind"] != 0:
+            continue
+        w_out = widths[t["level"]]
+        w_in = w_out * t["stride"]
+        assert t["tiling"].startswith("c16") == (w_in % 4 == 0 and w_out % 4 == 0), t
+    line = "[precision] 72x88 grid, bf16x3 requested: " + " | ".join(t["tiling"] for t in til)
+    print(line)
+    report(line)
+    pts = synth.lidar_cloud("eight_20cm", seed=5)
+    det, cnt = eng.infer_frame(torch.from_numpy(pts).cuda())
+    cnt = cnt.cpu().numpy()
+    r = oracle_frame(synth, "eight_20cm", pts, sd, over=over)
+    compare_frame(r, gpu_logits(eng, 0), det[:cnt[0]].cpu().numpy(), cnt, 0, "fused eight_20cm 72x88 grid, bf16x3 with fp32 fallback layers")
