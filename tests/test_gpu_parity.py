@@ -245,6 +245,33 @@ def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
         np.testing.assert_allclose(p["dir_preds"].cpu().numpy(), dr, rtol=0, atol=5e-5)
 
 
+C16_SHAPES = ["w2x2 t1x5 40x8 o2", "w2x2 t1x5 80x4 o2", "w2x2 t1x5 20x16 o2", "w4x1 t1x5 20x8 o2", "w4x1 t1x5 40x4 o2",
+              "w1x4 t2x5 80x8 o1", "w2x2 t2x5 40x8 o1", "w2x2 t2x5 20x16 o1", "w2x2 t1x5 40x8 o1", "w4x1 t1x5 20x8 o1"]
+
+
+@pytest.mark.parametrize("force,mode,tol", [(f, "bf16x3", 5e-4) for f in C16_SHAPES] + [("w2x2 t1x5 40x8 o2", "fp16", 0.03), ("w1x4 t2x5 80x8 o1", "bf16", 0.2)])
+def test_backbone_conv16_forced_tiling(force, mode, tol, fw, synth, monkeypatch):
+    """Every tile shape of the 16-bit operand convolution kernels (conv16.hip: one / two workgroups per CU, 64 / 128 rows, 20- to
+    80-pixel-wide tiles, stride 1 and 2) pinned on the golden small grid (maps 32 x 24 and 16 x 12: every tile overhangs the map,
+    so the masked edges and the zero padding are what is tested; the 8 x 6 level keeps its fp32 tilings -- width 6), whatever the
+    tuner would pick.  bf16x3 at a bar that only a correct kernel meets (observed 1.0e-4 on every shape); one shape each in fp16 / bf16."""
+    monkeypatch.setenv("PP_FORCE_VARIANT", force)
+    g = golden("backbone_small_instance")
+    cfg = small_cfg(synth, 64, 48)
+    fw["vg"].VoxelGenerator(cfg)
+    net = fw["shared"].PointPillars(cfg)
+    net.load_state_dict(synth.seeded_state_dict(0))
+    net.precision(mode)
+    til = net._eng.layer_tilings()
+    forced = [t["tiling"] for t in til if t["kind"] == 0 and force in t["tiling"]]
+    assert forced, [t["tiling"] for t in til]  # the shape really runs on at least one layer (rows must be a multiple of its 64 / 128)
+    y = net.rpn(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    dev = float(np.abs(y - g["y"]).max())
+    print(f"[conv16 forced] {force} {mode}: {len(forced)} layers, max deviation from the reference's backbone output {dev:.2e}")
+    assert dev <= tol, (force, mode, dev)
+    net.precision("fp32")
+
+
 @pytest.mark.parametrize("force,strips", [("wino4 tw4 bx2", "2"), ("wino4 tw8 bx1", "2"), ("wino4 tw8 bx2", "2"), ("wino4 tw4 bx2", "0")])
 def test_backbone_wino4_edge_maps(force, strips, fw, synth, monkeypatch):
     """wino4_mfma on maps that are no multiple of its tile: 72 x 88 canvas -> 36 x 44 (dwordx4 rows), 18 x 22 (width = 2 mod 4:
