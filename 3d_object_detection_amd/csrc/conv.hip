@@ -2983,7 +2983,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         if (p.pre == PRE_STATS) return pp_fail(ctx, PP_E_STATE, "conv16: the producer's statistics must be finalised to (scale, shift)");
         if ((Win & 3) || (Wout & 3) || (L.cin & 15) || (L.rows % v.bm)) return PP_E_ARG;
         const int total = pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph) * (L.rows / v.bm) * B;
-        int g = net->num_cu * (v.waves / 4); // workgroups per CU the variant is built for
+        int g = net->num_cu * (v.waves * 64 / v.threads); // workgroups per CU the variant is built for
 
         if (g > total) g = total;
         g = (g + 7) & ~7;

@@ -89,7 +89,12 @@ struct C16 {
     static constexpr int BM = WM * MT * 32;
     static constexpr int NPIX = PW * PH;
     static_assert(NPIX == 32 * WN * NT, "tile = whole N-tiles of 32 pixels");
-    static_assert(WM * WN == 4, "four waves, one per SIMD");
+    static constexpr int NW = WM * WN;   // waves per workgroup: 4 (one or two workgroups per CU) or 8 (one workgroup, two waves per SIMD)
+    static constexpr int T = 64 * NW;    // threads
+    static constexpr int TH = T / 2;     // threads staging one channel octet
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(NW == 4 || OCC == 2, "eight waves = two per SIMD: the register budget of OCC 2, single-buffered LDS");
+    static constexpr int WGS_PER_CU = OCC * 4 / NW;
     static_assert((PW * S) % 4 == 0, "tile origin on a pixel quad of the input");
     static constexpr int IH = (PH - 1) * S + 3;
     static constexpr int NQ = ceil_div((PW - 1) * S + 6, 4); // aligned pixel quads per patch row, from x = ox0*S - 4
@@ -108,10 +113,10 @@ struct C16 {
     static constexpr int X_UNITS = 2 * IH * RS;  // [k-half][row][col]
     static constexpr int W_UNITS = 9 * 2 * BM;   // [tap][k-half][row]
     static constexpr int POS = IH * NQ;          // (row, quad) positions per channel octet
-    static constexpr int XR = ceil_div(POS, 128); // staging rounds: waves {0,1} stage octet 0, waves {2,3} octet 1
-    static constexpr int WR = ceil_div(W_UNITS, 256);
+    static constexpr int XR = ceil_div(POS, TH); // staging rounds: the first half of the waves stages octet 0, the second half octet 1
+    static constexpr int WR = ceil_div(W_UNITS, T);
     static constexpr int RED_FLOATS = WN * BM * 2;
-    static constexpr int SCR_FLOATS = 4 * 32 * 36; // wave-private transpose tiles of the epilogue
+    static constexpr int SCR_FLOATS = NW * 32 * 36; // wave-private transpose tiles of the epilogue
     // OCC 2: the transpose tiles alias the (idle) operand buffers; a barrier closes every item
     static_assert(DB || (size_t)(X_UNITS + W_UNITS) * 16 >= (size_t)SCR_FLOATS * 4, "transpose tiles must fit the operand buffers");
     static constexpr size_t LDS_BYTES = DB ? (size_t)(2 * (X_UNITS + W_UNITS)) * 16 + (RED_FLOATS + SCR_FLOATS) * 4
@@ -124,7 +129,7 @@ struct C16 {
 // rows (ConvP::pmap / feat) instead of a dense canvas; a tile whose halo patch holds no pillar skips its MFMA loop.  A twin
 // instantiation, so that the dense stride-2 layers do not carry its registers.
 template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC, bool SPARSE = false>
-__global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
+__global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
 {
     using C = C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>;
     constexpr int NBUF = C::DB ? 2 : 1;
@@ -140,8 +145,8 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int n32 = lane & 31, kh = lane >> 5;
-    const int oct = wave >> 1;                 // channel octet this wave stages (uniform)
-    const int st = tid & 127;                  // staging thread index inside the octet's 128 threads
+    const int oct = wave / (C::NW / 2);        // channel octet this wave stages (uniform)
+    const int st = tid - oct * C::TH;          // staging thread index inside the octet's threads
 
     const int tiles_x = (p.Wout + PW - 1) / PW, tiles_y = (p.Hout + PH - 1) / PH;
     const int ncb = p.Cout / C::BM;
@@ -200,7 +205,7 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
         unsigned okm = 0u;    // bit r: the quad lies inside the map (else zero padding)
 #pragma unroll
         for (int r = 0; r < C::XR; ++r) {
-            const int pos = st + r * 128;
+            const int pos = st + r * C::TH;
             const int row = pos / C::NQ, q = pos - row * C::NQ;
             const int gy = iy0 + row, gx = qx0 + 4 * q;
             const bool have = pos < C::POS;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
             const u32x4* g = wsrc + (size_t)img * C::W_UNITS;
 #pragma unroll
             for (int r = 0; r < C::WR; ++r) {
-                const int e = tid + r * 256;
+                const int e = tid + r * C::T;
                 wv[r] = g[e < C::W_UNITS ? e : C::W_UNITS - 1];
             }
         };
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
             u32x4* wb = wl + buf * C::W_UNITS;
 #pragma unroll
             for (int r = 0; r < C::WR; ++r) {
-                const int e = tid + r * 256;
+                const int e = tid + r * C::T;
                 if (e < C::W_UNITS) wb[e] = wv[r];
             }
         };
@@ -479,7 +484,7 @@ __global__ void __launch_bounds__(256, OCC) conv16(const ConvP p)
                 }
             __syncthreads();
             double* gstat = p.stat_acc + (size_t)fr * p.stat_fs;
-            for (int lr = tid; lr < C::BM; lr += 256) {
+            for (int lr = tid; lr < C::BM; lr += C::T) {
                 double s = 0.0, q = 0.0;
 #pragma unroll
                 for (int w = 0; w < WN; ++w) {
@@ -510,8 +515,8 @@ Variant make_c16()
     Variant v;
     v.kern = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC>;
     if constexpr (STRIDE == 2) v.kern2 = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC, true>;
-    v.bm = C::BM; v.bmp = C::BM; v.pw = PW; v.ph = PH; v.kc = 16; v.threads = 256;
-    v.waves = 4 * OCC; v.pairs = MT * NT; // waves: per CU (the launcher sizes the persistent grid by it)
+    v.bm = C::BM; v.bmp = C::BM; v.pw = PW; v.ph = PH; v.kc = 16; v.threads = C::T;
+    v.waves = 4 * OCC; v.pairs = MT * NT; // waves: per CU (the launcher sizes the persistent grid: waves * 64 / threads workgroups per CU)
     v.lds = C::LDS_BYTES;
     v.wino = 5;
     v.prec = PREC;
@@ -522,7 +527,8 @@ Variant make_c16()
 template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC>
 void add_c16(std::vector<Variant>& m)
 {
-    if constexpr (C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>::LDS_BYTES * OCC <= 160 * 1024) m.push_back(make_c16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC>());
+    using C = C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>;
+    if constexpr (C::LDS_BYTES * C::WGS_PER_CU <= 160 * 1024) m.push_back(make_c16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC>());
 }
 
 // Tile menu.  A tile is PW x PH output pixels = whole 32-pixel N-tiles in row-major order, so PW only has to divide the map:
@@ -541,6 +547,9 @@ void menu_for(std::vector<Variant>& m)
         add_c16<1, PREC, 2, 2, 1, 5, 20, 16, 2>(m);  //  64   320
         add_c16<1, PREC, 4, 1, 1, 5, 20, 8, 2>(m);   // 128   160
         add_c16<1, PREC, 4, 1, 1, 5, 40, 4, 2>(m);   // 128   160
+        add_c16<1, PREC, 4, 2, 1, 5, 40, 8, 2>(m);   // 128   320   eight waves in ONE workgroup: one weight image and one patch per 320 / 640
+        add_c16<1, PREC, 4, 2, 1, 5, 20, 16, 2>(m);  // 128   320   pixels instead of one per 160 / 320 (the 128- / 256-channel layers are bound by
+        add_c16<1, PREC, 2, 4, 1, 5, 80, 8, 2>(m);   //  64   640   L2 -> CU bytes per flop, profiles/r03_conv16_stamps.txt)
         add_c16<1, PREC, 1, 4, 2, 5, 80, 8, 1>(m);   //  64   640
         add_c16<1, PREC, 2, 2, 2, 5, 40, 8, 1>(m);   // 128   320
         add_c16<1, PREC, 2, 2, 2, 5, 20, 16, 1>(m);  // 128   320
@@ -548,6 +557,7 @@ void menu_for(std::vector<Variant>& m)
         add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 2>(m);   //  64   320
         add_c16<2, PREC, 2, 2, 1, 5, 20, 16, 2>(m);  //  64   320
         add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 2>(m);   // 128   160
+        add_c16<2, PREC, 4, 2, 1, 5, 40, 8, 2>(m);   // 128   320   eight waves
         add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 1>(m);   //  64   320
         add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 1>(m);   // 128   160
     }

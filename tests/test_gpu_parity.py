@@ -246,7 +246,8 @@ def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
 
 
 C16_SHAPES = ["w2x2 t1x5 40x8 o2", "w2x2 t1x5 80x4 o2", "w2x2 t1x5 20x16 o2", "w4x1 t1x5 20x8 o2", "w4x1 t1x5 40x4 o2",
-              "w1x4 t2x5 80x8 o1", "w2x2 t2x5 40x8 o1", "w2x2 t2x5 20x16 o1", "w2x2 t1x5 40x8 o1", "w4x1 t1x5 20x8 o1"]
+              "w1x4 t2x5 80x8 o1", "w2x2 t2x5 40x8 o1", "w2x2 t2x5 20x16 o1", "w2x2 t1x5 40x8 o1", "w4x1 t1x5 20x8 o1",
+              "w4x2 t1x5 40x8 o2", "w4x2 t1x5 20x16 o2", "w2x4 t1x5 80x8 o2"]  # the last three: eight-wave workgroups
 
 
 @pytest.mark.parametrize("force,mode,tol", [(f, "bf16x3", 5e-4) for f in C16_SHAPES] + [("w2x2 t1x5 40x8 o2", "fp16", 0.03), ("w1x4 t2x5 80x8 o1", "bf16", 0.2)])
