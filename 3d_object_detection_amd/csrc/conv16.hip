@@ -316,15 +316,34 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
             }
         };
         using I0 = std::integral_constant<int, 0>;
-        // everything of a step in flight at once (one workgroup per CU; also the prologue of an item)
-        auto issue_all = [&](int step) __attribute__((always_inline)) {
-            pp_steps<0, XRL>([&](auto R) __attribute__((always_inline)) { issue_x(step, R, R); });
-            issue_w(step);
-            load_aff(step);
+        // Double-buffered path, bf16x3: the three steps of a 16-channel chunk c are (x_hi, w_hi), (x_hi, w_lo), (x_lo, w_hi), and
+        // patch and weight buffers are indexed SEPARATELY so that each step stages only the image that changes: x_hi lives in
+        // patch buffer 0 for steps 0 and 1, x_lo goes to buffer 1 during step 1; w_hi(c) lives in weight buffer c & 1 for steps
+        // 0 and 2, w_lo(c) goes to the other one during step 0; x_hi / w_hi of chunk c+1 are written during step 2 (into patch
+        // buffer 0 and weight buffer (c+1) & 1, both last read in step 1).  Four images staged per chunk instead of six.
+        auto need_x = [&](int step) __attribute__((always_inline)) { return !(C::DB && PASSES == 3) || (step % 3) != 1; };
+        auto need_w = [&](int step) __attribute__((always_inline)) { return !(C::DB && PASSES == 3) || (step % 3) != 2; };
+        auto xbuf_of = [&](int step) __attribute__((always_inline)) { return !C::DB ? 0 : PASSES == 3 ? ((step % 3) == 2 ? 1 : 0) : (step & 1); };
+        auto wbuf_of = [&](int step) __attribute__((always_inline)) {
+            if (!C::DB) return 0;
+            if (PASSES != 3) return step & 1;
+            const int c = step / 3, ps = step - 3 * c;
+            return ps == 1 ? 1 - (c & 1) : (c & 1);
         };
-        auto commit_all = [&](int step, int buf) __attribute__((always_inline)) {
-            pp_steps<0, XRL>([&](auto R) __attribute__((always_inline)) { commit_x(step, buf, R, R); });
-            commit_w(buf);
+        // everything a step needs in flight at once (one workgroup per CU; also the prologue of an item)
+        auto issue_all = [&](int step) __attribute__((always_inline)) {
+            if (need_x(step)) {
+                pp_steps<0, XRL>([&](auto R) __attribute__((always_inline)) { issue_x(step, R, R); });
+                load_aff(step);
+            }
+            if (need_w(step)) issue_w(step);
+        };
+        auto commit_all = [&](int step) __attribute__((always_inline)) {
+            if (need_x(step)) {
+                const int xb_ = xbuf_of(step);
+                pp_steps<0, XRL>([&](auto R) __attribute__((always_inline)) { commit_x(step, xb_, R, R); });
+            }
+            if (need_w(step)) commit_w(wbuf_of(step));
         };
         // single-buffered: rounds 1.. of the patch and the weight image, fetched and written one after the other
         auto stage_rest = [&](int step) __attribute__((always_inline)) {
@@ -336,13 +355,12 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         if (any) {
             C16_T(6)
             issue_all(0);
-            commit_all(0, 0);
+            commit_all(0);
             if constexpr (!C::DB) stage_rest(0);
             else if (nsteps > 1 && !(p.dbg & 1)) issue_all(1);
             __syncthreads();
             C16_T(0)
             for (int step = 0; step < nsteps; ++step) {
-                const int buf = C::DB ? (step & 1) : 0;
                 const bool stage = step + 1 < nsteps && !(p.dbg & 1);
                 if (stage) {
                     if constexpr (C::DB) {
@@ -351,7 +369,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                         // requests of step s+2 leave right behind it, so loads are in flight during every phase of the step
                         // (the first version requested at the top of a step and wrote at its end: one burst per step, and the
                         // memory pipe idle while the wave multiplied and converted)
-                        if (!(p.dbg & 128)) commit_all(step + 1, buf ^ 1);
+                        if (!(p.dbg & 128)) commit_all(step + 1);
                         C16_T(4)
                         if (step + 2 < nsteps) issue_all(step + 2);
                     } else {
@@ -360,8 +378,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                     }
                 }
                 C16_T(1)
-                const u32x4* xb = xl + buf * C::X_UNITS;
-                const u32x4* wb = wl + buf * C::W_UNITS;
+                const u32x4* xb = xl + xbuf_of(step) * C::X_UNITS;
+                const u32x4* wb = wl + wbuf_of(step) * C::W_UNITS;
                 // operand reads run ONE TAP AHEAD of the MFMAs that consume them (two register sets, order pinned with
                 // sched_barrier): left alone, hipcc issues a tap's ds_reads right in front of its MFMAs and every tap eats the LDS latency
                 u32x4 a[2][MT], b[2][NT];
