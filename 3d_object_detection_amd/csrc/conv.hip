@@ -2286,7 +2286,55 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         float* gout = p.out + (size_t)fr * p.out_fs;
         float* gbox = p.out_box ? p.out_box + (size_t)fr * p.box_fs : nullptr;
         float* gdir = p.out_dir ? p.out_dir + (size_t)fr * p.dir_fs : nullptr;
-        if (pok) {
+        bool up4_done = false;
+        if constexpr (EPI == EPI_UP4) {
+            if ((p.Wout & 3) == 0) {
+                // ConvTranspose k = s = 4: a lane's 4 pixels x 4 dx are 64 CONTIGUOUS output bytes (out[co][4y+dy][4x .. 4x+15]), but stored
+                // as it stands (one 16-byte piece per N-tile j) an instruction writes 16 bytes of each of 16 runs -- 64 scattered
+                // 16-byte requests.  The four lanes of a quad transpose their 4 x 4 pieces (out[k] on lane t = piece t of lane
+                // 4q + k's run: two butterfly stages of DPP quad permutes) so that instruction k writes WHOLE 64-byte runs, four
+                // lanes each.  All lanes take part (a DPP source must be live); a run beyond the map is dropped at the store.
+                up4_done = true;
+                int kq_e = kq;
+                asm volatile("" : "+v"(kq_e));
+                const int t_ = m & 3;
+                size_t ko[4];
+                bool kok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pk = pix0 + 4 * ((m & ~3) + k); // first pixel of lane 4q + k
+                    const int yk = pk / p.Wout, xk = pk - yk * p.Wout;
+                    kok[k] = pk < HW;
+                    ko[k] = (size_t)(4 * yk) * ((size_t)p.Wout * 4) + 4 * (size_t)xk + 4 * t_; // run of lane 4q + k starts at output x = 4 xk; this lane writes its piece t
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row0 = co0 + i * 16 + kq_e * 4;
+                    if (row0 >= p.Cout) continue; // wave-uniform per kq group of 16 lanes: quads stay whole
+                    const int co = row0 >> 4, dy = (row0 >> 2) & 3;
+                    f32x4 o4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a0 = acc[i][0][r], a1 = acc[i][1][r], a2 = acc[i][2][r], a3 = acc[i][3][r];
+                        if (pok) {
+                            ssum[i][0] += (a0 + a1) + (a2 + a3);
+                            ssq[i][0] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                        }
+                        // stage 1: swap the low bit of (register j, lane t); stage 2: the high bit
+                        const float x0 = dpp_f32<0xB1>(a1), x1 = dpp_f32<0xB1>(a0), x2 = dpp_f32<0xB1>(a3), x3 = dpp_f32<0xB1>(a2); // lane ^ 1
+                        const bool odd = t_ & 1, hi = t_ & 2;
+                        const float c0 = odd ? x0 : a0, c1 = odd ? a1 : x1, c2 = odd ? x2 : a2, c3 = odd ? a3 : x3;
+                        const float z0 = dpp_f32<0x4E>(c2), z1 = dpp_f32<0x4E>(c3), z2 = dpp_f32<0x4E>(c0), z3 = dpp_f32<0x4E>(c1); // lane ^ 2
+                        o4[0][r] = hi ? z0 : c0; o4[1][r] = hi ? z1 : c1; o4[2][r] = hi ? c2 : z2; o4[3][r] = hi ? c3 : z3;
+                    }
+                    float* ob = gout + (size_t)co * plane * 16 + (size_t)dy * ((size_t)p.Wout * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (kok[k]) *reinterpret_cast<f32x4*>(ob + ko[k]) = o4[k];
+                }
+            }
+        }
+        if (pok && !up4_done) {
             // the row-dependent addresses and biases are lane constants: without this the compiler hoists all of
             // them out of the item loop and spills them around the MFMA loop; recomputing per item is ~free
             int kq_e = kq;

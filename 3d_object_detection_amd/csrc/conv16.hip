@@ -9,8 +9,11 @@
 // * Direct convolution, no Winograd: at 16x the fp32-MFMA rate the matrix pipe is no longer what bounds these layers -- the
 //   64-channel layers at 400 x 400 are HBM-bound (82 MB in + out per frame against 11.8 GFLOP), the 256-channel ones at
 //   100 x 100 MFMA-bound, the 128-channel ones in between.
-// * One 4-wave workgroup per CU (one wave per SIMD, the whole register file), persistent over (frame, tile, cout block)
-//   items with XCD-contiguous ranges.  A workgroup tile is PW x PH output pixels = 32 * WN * NT pixels taken in row-major
+// * Persistent workgroups over (frame, tile, cout block) items with XCD-contiguous ranges, in three residency shapes the
+//   tuner chooses between: o1 = one 4-wave workgroup per CU (one wave per SIMD, the whole register file, 64 x 160-pixel wave
+//   tiles, double-buffered LDS); o2 = two 4-wave workgroups per CU, or ONE 8-wave workgroup (w4x2 / w2x4: one weight image
+//   and one patch per 320 / 640 pixels) -- two waves per SIMD, <= 256 registers, 32 x 160-pixel wave tiles, single-buffered
+//   LDS.  A workgroup tile is PW x PH output pixels = 32 * WN * NT pixels taken in row-major
 //   order: N-tile j of the tile = pixels 32 j .. 32 j + 31 of that order, so ANY tile width that divides the map works
 //   (400 = 5 * 80, 200 = 5 * 40, 100 = 5 * 20) and a wave's stores are runs of up to PW contiguous pixels of one channel.
 // * Per 16 input channels ("step"): the [IH][COLS] halo patch is fetched as aligned dwordx4 (4 pixels) of 8 channels per
@@ -24,8 +27,10 @@
 //   at the top of step s the data of step s+1 (requested a whole step earlier) is written to the other buffer and the
 //   loads of step s+2 are requested right behind it, then the 9 * MT * NT MFMAs of step s run.
 // * bf16x3: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), x * w ~ hi*hi + hi*lo + lo*hi as THREE steps per 16 channels
-//   with the same LDS footprint (the step re-stages the part it needs; the fp32 patch comes from L2 the second and third
-//   time), 3x the MFMAs of bf16 -- fp32-equivalent for this network (DESIGN.md tolerance table).
+//   with the same LDS footprint, 3x the MFMAs of bf16 -- fp32-equivalent for this network (DESIGN.md tolerance table).
+//   Double-buffered path: patch and weight buffers are indexed separately, so a step stages only the image that changes
+//   (x_hi + w_hi, then w_lo, then x_lo: four images per chunk; the fp32 patch comes from L2 the second time); the
+//   single-buffered path re-stages both images every step.
 // * Epilogue: residual add, fp32 NCHW stores through a buffer descriptor (lane offset in a VGPR, the channel's plane offset
 //   in an SGPR, out-of-map lanes parked beyond the descriptor's range), per-channel sum / sum of squares for the consumer's
 //   InstanceNorm (fp32 over the wave's <= NT*32 pixels, then fp64 atomics into the 8 replicated accumulators).
