@@ -22,7 +22,7 @@ int pp_fail(pp_ctx* ctx, int code, const char* msg)
 }
 
 extern "C" const char* pp_last_error(pp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-extern "C" int pp_version(void) { return 2; }
+extern "C" int pp_version(void) { return 3; } // round 3: launch plan keyed on max_batch, 16-bit conv kernels, pp_select_candidates
 
 int pp_stage_mark(pp_ctx* ctx, hipStream_t stream, int id)
 {
