@@ -2046,9 +2046,14 @@ __device__ __forceinline__ f32x4 mfma_lp(const s16x4 a, const s16x4 b, const f32
     else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-template <int MT, int NT, int EPI, int PREC = 0>
+// IO16 (pp_set_precision 4, "fp16s": fp16 operands AND fp16 storage of the [320,H,W] concat buffer the upsamplers write and the head
+// reads -- the largest tensor of the network, 205 MB per frame in fp32): bit 0 = the input tensor is fp16, bit 1 = the output is.
+template <int MT, int NT, int EPI, int PREC = 0, int IO16 = 0>
 __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 {
+    constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
+    static_assert(IO16 == 0 || PREC != 0, "16-bit storage comes with the 16-bit operand path");
+    static_assert(!OUT16 || EPI != EPI_HEAD, "the head's logits stay fp32");
     constexpr int BM = MT * 16;
     constexpr int BMP = BM + ((BM % 32 == 0) ? 16 : 0);
     constexpr int PD = (MT >= 8) ? 4 : 8; // B-operand ring depth (steps in flight); even, K % (4 * PD) == 0; 128 accumulator registers leave room for 4
@@ -2131,10 +2136,10 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         const int f_ = __builtin_amdgcn_readfirstlane(it / items_per_frame); // the division runs on the VALU: pin the
         const int px_ = __builtin_amdgcn_readfirstlane((it - f_ * items_per_frame) * (NT * 16)) + 4 * m; // results in SGPRs
         // descriptor base pinned to SGPRs (a VGPR-resident descriptor costs a waterfall loop per load)
-        const uint64_t bp_ = (uint64_t)(p.in + (size_t)f_ * p.in_fs);
+        const uint64_t bp_ = IN16 ? (uint64_t)(reinterpret_cast<const _Float16*>(p.in) + (size_t)f_ * p.in_fs) : (uint64_t)(p.in + (size_t)f_ * p.in_fs);
         const uint64_t bps_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bp_);
         rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(bps_), 0, 0x7FFFFFFF, 0x00020000);
-        bvoff = ((unsigned)kq * (unsigned)plane + (unsigned)(px_ < HW ? px_ : 0)) * 4u;
+        bvoff = ((unsigned)kq * (unsigned)plane + (unsigned)(px_ < HW ? px_ : 0)) * (IN16 ? 2u : 4u);
     };
 #define G1_LOADB(S, SLOT) bq[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff, (unsigned)(S) * bstep, 0));
 #define G1_PREP(S, SLOT, PAR)                                                                    \
@@ -2233,12 +2238,19 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             //      loads channels kq*4 .. kq*4+3 of the block for its 4 pixels (4 dwordx4, block kb+1 in flight behind block kb),
             //      normalises in fp32, packs 4 channels of one pixel into one B operand (two v_cvt_pk_bf16_f32) ----
             set_load_item(item);
-            const unsigned bvq = bvoff + (unsigned)kq * 3u * (unsigned)plane * 4u; // (kq*4*plane + pixel)*4: bvoff already holds kq*plane
-            const unsigned cstep = (unsigned)plane * 4u;                            // bytes between channels
+            constexpr unsigned EB = IN16 ? 2u : 4u;                                 // bytes per input element
+            const unsigned bvq = bvoff + (unsigned)kq * 3u * (unsigned)plane * EB; // (kq*4*plane + pixel)*EB: bvoff already holds kq*plane
+            const unsigned cstep = (unsigned)plane * EB;                            // bytes between channels
             const uint2* wl2 = reinterpret_cast<const uint2*>(wl);
             const int nkb = K / 16;
             f32x4 q0[4], q1[4];
-#define G1_LP_LOAD(Q, KB) _Pragma("unroll") for (int t = 0; t < 4; ++t) Q[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0));
+            // fp16 input: a lane's 4 pixels of a channel are 8 bytes; they are widened to fp32 as they arrive, so the block code is shared
+#define G1_LP_LOAD(Q, KB) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                     \
+        if constexpr (IN16) {                                                                                               \
+            const f16x4_t h_ = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_raw_buffer_load_b64(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
+            Q[t] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};                                            \
+        } else Q[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
+    }
 #define G1_LP_BLOCK(Q, KB)                                                                       \
     {                                                                                            \
         f32x4 sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = (f32x4){0.f, 0.f, 0.f, 0.f};              \
@@ -2283,7 +2295,16 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
         }
 
         // ---- epilogue of this item (lane m owns pixels pxb .. pxb+3, one per N-tile) ----
-        float* gout = p.out + (size_t)fr * p.out_fs;
+        // OUT16: `gout` counts in ELEMENTS of the output tensor either way; st4 rounds four values to fp16 and stores 8 bytes
+        float* gout = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out) + (size_t)fr * p.out_fs) : p.out + (size_t)fr * p.out_fs;
+        auto st4 = [&](size_t off, const f32x4 v) __attribute__((always_inline)) {
+            if constexpr (OUT16) {
+                const uint2 h = {pk_f16(v[0], v[1]), pk_f16(v[2], v[3])};
+                *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(gout) + off) = h;
+            } else {
+                *reinterpret_cast<f32x4*>(gout + off) = v;
+            }
+        };
         float* gbox = p.out_box ? p.out_box + (size_t)fr * p.box_fs : nullptr;
         float* gdir = p.out_dir ? p.out_dir + (size_t)fr * p.dir_fs : nullptr;
         bool up4_done = false;
@@ -2327,10 +2348,10 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                         const float z0 = dpp_f32<0x4E>(c2), z1 = dpp_f32<0x4E>(c3), z2 = dpp_f32<0x4E>(c0), z3 = dpp_f32<0x4E>(c1); // lane ^ 2
                         o4[0][r] = hi ? z0 : c0; o4[1][r] = hi ? z1 : c1; o4[2][r] = hi ? c2 : z2; o4[3][r] = hi ? c3 : z3;
                     }
-                    float* ob = gout + (size_t)co * plane * 16 + (size_t)dy * ((size_t)p.Wout * 4);
+                    const size_t ob = (size_t)co * plane * 16 + (size_t)dy * ((size_t)p.Wout * 4);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (kok[k]) *reinterpret_cast<f32x4*>(ob + ko[k]) = o4[k];
+                        if (kok[k]) st4(ob + ko[k], o4[k]);
                 }
             }
         }
@@ -2352,7 +2373,7 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const f32x4 x = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-                        *reinterpret_cast<f32x4*>(gout + (size_t)(row0 + r) * plane + pxb) = x;
+                        st4((size_t)(row0 + r) * plane + pxb, x);
                         ssum[i][r] += (x[0] + x[1]) + (x[2] + x[3]);
                         ssq[i][r] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
                     }
@@ -2362,11 +2383,11 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
                     if (row4) {
                         // the lane's 4 pixels are 8 consecutive floats of output rows 2y and 2y+1: two dwordx4 per row,
                         // 512 contiguous bytes per 16 lanes (the per-pixel float2 stores left 8 of every 32 bytes per instruction)
-                        float* o = gout + (size_t)co * plane * 4 + (size_t)(2 * py_) * W2 + 2 * px_;
-                        *reinterpret_cast<f32x4*>(o) = (f32x4){acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]};
-                        *reinterpret_cast<f32x4*>(o + 4) = (f32x4){acc[i][2][0], acc[i][2][1], acc[i][3][0], acc[i][3][1]};
-                        *reinterpret_cast<f32x4*>(o + W2) = (f32x4){acc[i][0][2], acc[i][0][3], acc[i][1][2], acc[i][1][3]};
-                        *reinterpret_cast<f32x4*>(o + W2 + 4) = (f32x4){acc[i][2][2], acc[i][2][3], acc[i][3][2], acc[i][3][3]};
+                        const size_t o = (size_t)co * plane * 4 + (size_t)(2 * py_) * W2 + 2 * px_;
+                        st4(o, (f32x4){acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]});
+                        st4(o + 4, (f32x4){acc[i][2][0], acc[i][2][1], acc[i][3][0], acc[i][3][1]});
+                        st4(o + W2, (f32x4){acc[i][0][2], acc[i][0][3], acc[i][1][2], acc[i][1][3]});
+                        st4(o + W2 + 4, (f32x4){acc[i][2][2], acc[i][2][3], acc[i][3][2], acc[i][3][3]});
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -2437,13 +2458,15 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
 // y = relu(x*scale+shift) (scale/shift from the producer's statistics), plus statistics of y.
 // Used for the [conv, norm, relu] head of each block, whose output is both a residual and the
 // input of the next InstanceNorm (pointpillars8_shared.py:133-137).
+// x16: the input tensor is fp16 (the concat buffer under pp_set_precision 4); y is fp32 either way
 __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
                                                        int pre, const double* __restrict__ pre_acc,
                                                        const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
                                                        double inv_n, float eps, double* __restrict__ stat_acc,
-                                                       size_t x_fs, size_t acc_fs)
+                                                       size_t x_fs, size_t acc_fs, int x16)
 {
     const int c = blockIdx.y;
+    const _Float16* xh = reinterpret_cast<const _Float16*>(x) + blockIdx.z * x_fs;
     x += blockIdx.z * x_fs;
     y += blockIdx.z * x_fs;
     if (pre_acc) pre_acc += blockIdx.z * acc_fs;
@@ -2471,8 +2494,13 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
         const float4* xi = reinterpret_cast<const float4*>(x + (size_t)c * HW);
         float4* yo = reinterpret_cast<float4*>(y + (size_t)c * HW);
         const int n4 = HW >> 2;
+        const uint2* xi16 = reinterpret_cast<const uint2*>(xh + (size_t)c * HW);
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-            float4 v = xi[i];
+            float4 v;
+            if (x16) {
+                const f16x4_t h = __builtin_bit_cast(f16x4_t, xi16[i]);
+                v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+            } else v = xi[i];
             v.x = fmaxf(fmaf(v.x, sc, sh), 0.f);
             v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
             v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
@@ -2486,7 +2514,7 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
         const float* xi = x + (size_t)c * HW;
         float* yo = y + (size_t)c * HW;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-            const float v = fmaxf(fmaf(xi[i], sc, sh), 0.f);
+            const float v = fmaxf(fmaf(x16 ? (float)xh[(size_t)c * HW + i] : xi[i], sc, sh), 0.f);
             yo[i] = v;
             s += v;
             q += v * v;
@@ -2570,17 +2598,19 @@ Variant make_wres()
     return v;
 }
 
-template <int MT, int NT, int EPI, int PREC = 0>
+template <int MT, int NT, int EPI, int PREC = 0, int IO16 = 0>
 Variant make_g1()
 {
     Variant v;
-    v.kern = gemm1x1<MT, NT, EPI, PREC>;
+    v.kern = gemm1x1<MT, NT, EPI, PREC, IO16>;
     v.prec = PREC;
+    v.io16 = IO16;
     v.bm = MT * 16; v.bmp = v.bm + ((v.bm % 32 == 0) ? 16 : 0); v.pw = NT * 16; v.ph = 1; v.kc = 4; v.threads = 512;
     v.waves = 8; v.pairs = MT * NT;
     v.lds = 0; // depends on K: set per layer
     v.wino = 3;
-    if (PREC) snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d p%d", MT, NT, EPI, PREC);
+    if (IO16) snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d h%d p%d", MT, NT, EPI, IO16, PREC);
+    else if (PREC) snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d p%d", MT, NT, EPI, PREC);
     else snprintf(v.name, sizeof(v.name), "g1x1 m%d n%d e%d", MT, NT, EPI);
     return v;
 }
@@ -2619,6 +2649,8 @@ struct pp_net {
     float* ones = nullptr;
     float* zeros = nullptr;
     int num_cu = 256;
+    int eff_prec = 0;   // the precision the launch plan is built for: ctx->precision, except 4 -> 3 when the concat buffer cannot be fp16
+    bool up16 = false;  // pp_set_precision 4 and every upsampler / the head on an io16 tiling: the concat buffer `up` holds fp16
     int w4_strips = -1; // PP_W4_STRIPS, read once at pp_create: -1 cost model, 0 never, 2 whenever whole main tiles exist (parity tests of the strip tiles)
 };
 
@@ -2651,13 +2683,15 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-template <int PREC>
+// S16 (pp_set_precision 4): the concat buffer is stored in fp16 -- the upsamplers write it (OUT16), the head reads it (IN16)
+template <int PREC, bool S16 = false>
 void lp_menu(int kind, int up, std::vector<Variant>& menu)
 {
-    if (kind == 2) { menu.push_back(make_g1<6, 4, EPI_HEAD, PREC>()); menu.push_back(make_g1<3, 4, EPI_HEAD, PREC>()); }
-    else if (up == 1) { menu.push_back(make_g1<4, 4, EPI_PLAIN, PREC>()); menu.push_back(make_g1<2, 4, EPI_PLAIN, PREC>()); }
-    else if (up == 2) { menu.push_back(make_g1<4, 4, EPI_UP2, PREC>()); menu.push_back(make_g1<8, 4, EPI_UP2, PREC>()); }
-    else { menu.push_back(make_g1<4, 4, EPI_UP4, PREC>()); menu.push_back(make_g1<8, 4, EPI_UP4, PREC>()); }
+    constexpr int HI = S16 ? 1 : 0, DO = S16 ? 2 : 0;
+    if (kind == 2) { menu.push_back(make_g1<6, 4, EPI_HEAD, PREC, HI>()); menu.push_back(make_g1<3, 4, EPI_HEAD, PREC, HI>()); }
+    else if (up == 1) { menu.push_back(make_g1<4, 4, EPI_PLAIN, PREC, DO>()); menu.push_back(make_g1<2, 4, EPI_PLAIN, PREC, DO>()); }
+    else if (up == 2) { menu.push_back(make_g1<4, 4, EPI_UP2, PREC, DO>()); menu.push_back(make_g1<8, 4, EPI_UP2, PREC, DO>()); }
+    else { menu.push_back(make_g1<4, 4, EPI_UP4, PREC, DO>()); menu.push_back(make_g1<8, 4, EPI_UP4, PREC, DO>()); }
 }
 
 void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true, int prec = 0)
@@ -2668,11 +2702,12 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
     // conv16.hip.  A layer whose shape none of them takes (autotune_layer checks variant_ok / shape_ok) falls back to the
     // fp32 menu below, and pp_layer_tilings shows it.
     if (prec && g1ok && (kind == 1 || (kind == 2 && head9))) {
-        if (prec == 1) lp_menu<1>(kind, up, menu); else if (prec == 2) lp_menu<2>(kind, up, menu); else lp_menu<3>(kind, up, menu);
+        if (prec == 1) lp_menu<1>(kind, up, menu); else if (prec == 2) lp_menu<2>(kind, up, menu); else if (prec == 3) lp_menu<3>(kind, up, menu);
+        else lp_menu<3, true>(kind, up, menu);
         return;
     }
     if (prec && kind == 0 && cin % 16 == 0) {
-        conv16_menu(stride, prec, menu);
+        conv16_menu(stride, prec == 4 ? 3 : prec, menu); // fp16s: the convolutions are the fp16-operand kernels, their tensors stay fp32
         return;
     }
     if (kind == 2) {
@@ -2734,7 +2769,8 @@ bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4
 // shape limits of a tiling family: wino4_mfma stores float2 rows (even output width); gemm1x1 feeds four N-tiles from one
 // dwordx4 of 4 consecutive pixels of the input plane (pixel count a multiple of 4 -- a 9 x 11 map has 99)
 // conv16 fetches its patches as aligned pixel quads and stores pixel quads (input and output width multiples of 4)
-bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
+// (gemm1x1 with a 16-bit tensor has no path for maps that are not a multiple of 4 wide)
+bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 3 && v.io16 && (Wout & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -3127,6 +3163,11 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
 }
 
 
+__global__ void __launch_bounds__(256) f32_to_f16(const float* __restrict__ x, _Float16* __restrict__ y, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (_Float16)x[i];
+}
+
 __global__ void __launch_bounds__(256) fill_pattern(float* __restrict__ x, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -3199,14 +3240,15 @@ constexpr size_t TUNE_OUT_FS = 0, TUNE_IN_FS = 0; // 0: natural per-frame stride
 int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, float* tin, float* tout, bool verbose, bool measure = true)
 {
     pp_net* net = (pp_net*)ctx->net;
+    const int eprec = net->eff_prec;
     char sig[160];
     std::vector<Variant> menu;
     const int rows_ = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     auto legal = [&](const Variant& v) {
         return variant_ok(v, rows_) && shape_ok(v, Hin, Win, Wout) && ((v.wino == 3) ? g1_lds(v, L.cin) : v.lds) <= (size_t)160 * 1024;
     };
-    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, ctx->precision);
-    if (ctx->precision) {
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, eprec);
+    if (eprec) {
         // a shape none of the reduced-precision tilings takes (odd maps, Cin not a multiple of 16 / 32) runs its fp32 tilings:
         // pp_layer_tilings reports what really runs
         bool any = false;
@@ -3218,15 +3260,15 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     }
     if (!measure) { // no on-device tuning (PP_AUTOTUNE=0 / maps the tuner's buffers do not fit): fp32 keeps pick_variant's choice,
                     // a reduced-precision mode takes the first legal entry of its menu
-        if (ctx->precision)
+        if (eprec)
             for (const Variant& v : menu)
-                if (legal(v) && v.prec == ctx->precision) { L.var = v; return 0; }
+                if (legal(v) && v.prec == (eprec == 4 ? 3 : eprec)) { L.var = v; return 0; }
         return 0;
     }
     // the key carries the library version and the menu size (an entry of another build's menu is not trusted), not the
     // device index: the GPUs of a node are identical, and ranks must be able to share rank 0's table
     snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d p%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
-             ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES, ctx->precision);
+             ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES, eprec);
     const int rows = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
@@ -3447,6 +3489,10 @@ int pp_net_commit(pp_ctx* ctx)
         const int H = ctx->H, W = ctx->W;
         float *tin = nullptr, *tout = nullptr;
         const bool can_tune = tune && (H % 4 == 0) && (W % 4 == 0);
+        // fp16 storage of the concat buffer needs every upsampler and the head on gemm1x1's 16-bit-tensor tilings: maps a multiple of
+        // 4 wide at all three levels and the 9-anchor head; otherwise mode 4 runs as mode 3 (fp16 operands, fp32 tensors)
+        net->up16 = ctx->precision == 4 && (W % 16 == 0) && ((H * W) % 64 == 0) && ctx->cfg.num_anchor_per_loc == 9;
+        net->eff_prec = (ctx->precision == 4 && !net->up16) ? 3 : ctx->precision;
         if (can_tune) {
             const size_t nin = std::max((size_t)64 * ctx->gx * ctx->gy, (size_t)320 * H * W);
             const int tb = ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES;
@@ -3459,7 +3505,7 @@ int pp_net_commit(pp_ctx* ctx)
             {
                 const int h = H >> L.level, w = W >> L.level;
                 const int hin = (L.kind == 0 && L.stride == 2) ? h * 2 : h, win = (L.kind == 0 && L.stride == 2) ? w * 2 : w;
-                if (!can_tune && ctx->precision == 0) L.var = pick_variant(L.kind, L.stride, L.up, (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout), h, w, ctx->cfg.num_anchor_per_loc == 9);
+                if (!can_tune && net->eff_prec == 0) L.var = pick_variant(L.kind, L.stride, L.up, (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout), h, w, ctx->cfg.num_anchor_per_loc == 9);
                 rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose, can_tune);
                 if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
             }
@@ -3470,6 +3516,10 @@ int pp_net_commit(pp_ctx* ctx)
             if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
         }
         if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); tune_cache_save(); }
+        if (net->up16)
+            for (const Layer& L : net->layers)
+                if ((L.kind == 1 && L.var.io16 != 2) || (L.kind == 2 && L.var.io16 != 1))
+                    return pp_fail(ctx, PP_E_STATE, "fp16s: an upsampler or the head did not get a 16-bit-tensor tiling (PP_FORCE_VARIANT?)");
     }
     if (ctx->cfg.norm_kind == 1) {
         for (int b = 0; b < 3; ++b) {
@@ -3543,12 +3593,12 @@ double* stat_slot(pp_ctx* ctx, int site)
 }
 
 int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const NormRef& pre, double* stat, hipStream_t stream,
-                     int B = 1)
+                     int B = 1, int x16 = 0)
 {
     int bx = pp_div_up(HW / 4, 256 * 4);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(norm_relu_stats, dim3(bx, C, B), dim3(256), 0, stream, x, y, C, HW, pre.mode, pre.acc, pre.scale,
-                       pre.shift, pre.inv_n, 1e-3f, stat, (size_t)C * HW, STAT_FS);
+                       pre.shift, pre.inv_n, 1e-3f, stat, (size_t)C * HW, STAT_FS, x16);
     PP_HIP(hipGetLastError());
     return 0;
 }
@@ -3612,7 +3662,10 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream
         {
             const Layer& L = net->layers[li++];
             double* st = stat_slot(ctx, 7);
-            if ((rc = launch_conv(ctx, L, cur, h, w, net->up + (size_t)up_coff[b] * H * W, nullptr, raw, st ? st + (size_t)up_coff[b] * 2 : nullptr,
+            // the block's channel slice of the concat buffer (element offsets: the buffer holds fp16 under pp_set_precision 4)
+            float* slice = net->up16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(net->up) + (size_t)up_coff[b] * H * W)
+                                     : net->up + (size_t)up_coff[b] * H * W;
+            if ((rc = launch_conv(ctx, L, cur, h, w, slice, nullptr, raw, st ? st + (size_t)up_coff[b] * 2 : nullptr,
                                   320, h, w, stream, nullptr, nullptr, nb, up_fs))) return rc;
         }
         x = cur;
@@ -3646,7 +3699,7 @@ extern "C" int pp_backbone(pp_ctx* ctx, const float* canvas, float* rpn_out, voi
     pp_net* net = (pp_net*)ctx->net;
     const int HW = ctx->H * ctx->W;
     // stand-alone API: materialise relu(norm(up)) as the reference's RPN.forward returns it
-    return launch_norm_relu(ctx, net->up, rpn_out, 320, HW, norm_ref(ctx, 7, 320, 0, (size_t)HW), nullptr, stream);
+    return launch_norm_relu(ctx, net->up, rpn_out, 320, HW, norm_ref(ctx, 7, 320, 0, (size_t)HW), nullptr, stream, 1, net->up16 ? 1 : 0);
 }
 
 extern "C" int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box, float* dir, void* stream_)
@@ -3656,6 +3709,12 @@ extern "C" int pp_head(pp_ctx* ctx, const float* rpn_out, float* cls, float* box
     if (!ctx->weights_ready) return pp_fail(ctx, PP_E_STATE, "pp_head: weights not committed");
     if (!rpn_out || !cls || !box || !dir) return pp_fail(ctx, PP_E_ARG, "pp_head: null pointer");
     NormRef raw; // rpn_out is already normalised + ReLU'd
+    pp_net* net = (pp_net*)ctx->net;
+    if (net->up16) { // the head's tiling reads an fp16 tensor: round the caller's fp32 features into the (idle) concat buffer first
+        const size_t n = (size_t)320 * ctx->H * ctx->W;
+        hipLaunchKernelGGL(f32_to_f16, dim3(2048), dim3(256), 0, stream, rpn_out, reinterpret_cast<_Float16*>(net->up), n);
+        return pp_head_impl(ctx, net->up, raw, cls, box, dir, 1, stream);
+    }
     return pp_head_impl(ctx, rpn_out, raw, cls, box, dir, 1, stream);
 }
 
@@ -3681,7 +3740,9 @@ extern "C" int pp_fetch_frame_tensor(pp_ctx* ctx, int frame, int kind, void* dst
     case 4: {
         NormRef pre = norm_ref(ctx, 7, 320, 0, HW);
         if (pre.mode == PRE_STATS) pre.acc += (size_t)frame * STAT_FS;
-        return launch_norm_relu(ctx, net->up + (size_t)frame * 320 * HW, (float*)dst, 320, (int)HW, pre, nullptr, stream);
+        const float* src_ = net->up16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(net->up) + (size_t)frame * 320 * HW)
+                                      : net->up + (size_t)frame * 320 * HW;
+        return launch_norm_relu(ctx, src_, (float*)dst, 320, (int)HW, pre, nullptr, stream, 1, net->up16 ? 1 : 0);
     }
     case 5: src = ctx->f_feat + frame * mv * 64; bytes = mv * 64 * 4; break;
     case 6: src = ctx->f_coors + frame * mv * 3; bytes = mv * 12; break;

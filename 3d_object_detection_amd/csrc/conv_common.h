@@ -110,7 +110,8 @@ struct Variant { // one compiled tiling of conv_mfma
     char name[48];
     int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
     int cin = 0;  // wino == 2: compiled for exactly this Cin
-    int prec = 0; // wino == 3: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16
+    int prec = 0; // wino == 3 / 5: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16, 3 fp16 operands
+    int io16 = 0; // wino == 3: bit 0 = the input tensor is fp16, bit 1 = the output tensor is (the concat buffer under pp_set_precision 4)
 };
 
 

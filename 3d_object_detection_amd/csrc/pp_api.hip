@@ -225,7 +225,7 @@ extern "C" void pp_destroy(pp_ctx* ctx)
 
 extern "C" int pp_set_precision(pp_ctx* ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 3) return pp_fail(ctx, PP_E_ARG, "pp_set_precision: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16) or 3 (fp16)");
+    if (!ctx || mode < 0 || mode > 4) return pp_fail(ctx, PP_E_ARG, "pp_set_precision: mode must be 0 (fp32), 1 (bf16x3), 2 (bf16), 3 (fp16) or 4 (fp16s)");
     if (ctx->precision != mode) ctx->weights_ready = false; // the tilings and weight images are chosen at pp_commit_weights
     ctx->precision = mode;
     return 0;

@@ -139,7 +139,7 @@ def _stream():
 class Engine:
     """Owns a pp_ctx.  Created lazily through engine_for(config)."""
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3, "fp16s": 4}
 
     def __init__(self, config, device_index=0, norm="instance", max_points=None, max_batch=None, precision="fp32"):
         self.lib = _lib.load()
@@ -211,7 +211,8 @@ class Engine:
     # ------------------------------------------------------------------ weights
     def set_precision(self, mode):
         """MFMA operand type of the convolutions, upsamplers and head: "fp32" (exact, default), "bf16x3" (split-bf16, fp32-equivalent),
-        "fp16" / "bf16" (reduced-precision deploy modes).  Re-commits the loaded weights for the new tilings."""
+        "fp16" / "bf16" (reduced-precision deploy modes), "fp16s" (fp16 operands and fp16 STORAGE of the 320-channel concat
+        buffer between the upsamplers and the head).  Re-commits the loaded weights for the new tilings."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _lib.check(self.lib.pp_set_precision(self.ctx, self.PRECISIONS[mode]), self.ctx, "pp_set_precision")

@@ -211,7 +211,7 @@ def main():
                     help="independent frames per pass per GPU (pp_infer_batch: frame = grid.z of the conv launches); weak scaling")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="TOTAL frames per step, sharded by frame index over the ranks (strong scaling; BASELINE config 5: 64)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16", "fp16s"],
                     help="MFMA operand type of convolutions, upsamplers and head (pp_set_precision); anything but fp32 prints a TAGGED line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)

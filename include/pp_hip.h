@@ -70,8 +70,10 @@ int pp_commit_weights(pp_ctx* ctx);
  *   0 fp32 MFMA (default, exact, the parity path);
  *   1 split-bf16 "bf16x3" (x = hi + lo, three bf16 MFMAs per product, fp32 accumulation: fp32-equivalent for this network,
  *     meets the fp32 parity bar -- DESIGN.md);
- *   2 bf16 operands;   3 fp16 operands (the reference's deploy arithmetic) -- own tolerance table in DESIGN.md.
- * Accumulation is fp32 and activations stay fp32 NCHW in HBM in every mode (normalise + ReLU in fp32, round while staging).
+ *   2 bf16 operands;   3 fp16 operands (the reference's deploy arithmetic) -- own tolerance table in DESIGN.md;
+ *   4 "fp16s": mode 3 plus fp16 STORAGE of the [320,H,W] concat buffer between the upsamplers and the head (the largest tensor of
+ *     the network; TensorRT FP16 engines keep fp16 tensors between layers) -- runs as mode 3 where the maps are not multiples of 16.
+ * Accumulation is fp32 and every other activation stays fp32 NCHW in HBM (normalise + ReLU in fp32, round while staging).
  * A layer whose shape none of the 16-bit tilings takes (maps not a multiple of 4 wide, Cin not a multiple of 16 / 32) keeps its
  * fp32 tiling: pp_layer_tilings reports what runs.  Call before pp_commit_weights (a change of mode invalidates the committed
  * weights until the next commit). */

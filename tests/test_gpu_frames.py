@@ -279,7 +279,7 @@ def test_nuscene_10class_head(synth):
 
 # tolerance table of the reduced-precision deploy modes: max |logit - fp32 path's logit| and the share of the
 # fp32 path's detections that must be reproduced within 0.1 m / 0.05 score
-PRECISION_BARS = {"bf16x3": (1e-3, None), "fp16": (0.03, 0.95), "bf16": (0.15, 0.85)}
+PRECISION_BARS = {"bf16x3": (1e-3, None), "fp16": (0.03, 0.95), "fp16s": (0.03, 0.95), "bf16": (0.15, 0.85)}
 
 
 def _reproduced(ref_rows, rows):
@@ -302,11 +302,13 @@ def test_reduced_precision_modes(synth):
     cloud = torch.from_numpy(pts).cuda()
     r = oracle_frame(synth, "nuscene", pts, sd)
     out = {}
-    for mode in ("fp32", "bf16x3", "fp16", "bf16"):
+    for mode in ("fp32", "bf16x3", "fp16", "fp16s", "bf16"):
         eng = eng_mod.Engine(make_cfg(synth, "nuscene"), precision=mode)
         eng.load_state_dict(sd)
         til = eng.layer_tilings()
-        code = eng.PRECISIONS[mode]
+        code = min(eng.PRECISIONS[mode], 3)  # fp16s: the fp16-operand tilings, with 16-bit-tensor variants (h1 / h2) around the concat buffer
+        if mode == "fp16s":
+            assert all((" h2 " in t["tiling"]) for t in til if t["kind"] == 1) and all((" h1 " in t["tiling"]) for t in til if t["kind"] == 2), til
         for t in til:  # what really runs: every conv on conv16, every 1x1 contraction on the reduced-precision gemm1x1
             name = t["tiling"]
             if mode == "fp32":
@@ -335,7 +337,7 @@ def test_reduced_precision_modes(synth):
             assert frac >= share, (mode, frac)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "fp16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16", "fp16s"])
 def test_reduced_precision_bench_path(mode, synth, eight_ref):
     """The 16-bit operand kernels on the workload bench.py times (eight_20cm, pp_infer_batch, sparse first conv through conv16's
     twin kernel, 400 / 200 / 100 maps): bf16x3 against the oracle at the fp32 bar; fp16 against the oracle's logits at its own bar
