@@ -2463,10 +2463,11 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
                                                        int pre, const double* __restrict__ pre_acc,
                                                        const float* __restrict__ pre_scale, const float* __restrict__ pre_shift,
                                                        double inv_n, float eps, double* __restrict__ stat_acc,
-                                                       size_t x_fs, size_t acc_fs, int x16)
+                                                       size_t x_fs, size_t acc_fs, int x16, int y16)
 {
     const int c = blockIdx.y;
     const _Float16* xh = reinterpret_cast<const _Float16*>(x) + blockIdx.z * x_fs;
+    _Float16* yh = reinterpret_cast<_Float16*>(y) + blockIdx.z * x_fs;
     x += blockIdx.z * x_fs;
     y += blockIdx.z * x_fs;
     if (pre_acc) pre_acc += blockIdx.z * acc_fs;
@@ -2505,7 +2506,8 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
             v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
             v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
             v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-            yo[i] = v;
+            if (y16) reinterpret_cast<uint2*>(yh + (size_t)c * HW)[i] = (uint2){pk_f16(v.x, v.y), pk_f16(v.z, v.w)}; // statistics below: of the fp32 values
+            else yo[i] = v;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             if (++it == 8) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
@@ -2515,7 +2517,7 @@ __global__ void __launch_bounds__(256) norm_relu_stats(const float* __restrict__
         float* yo = y + (size_t)c * HW;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
             const float v = fmaxf(fmaf(x16 ? (float)xh[(size_t)c * HW + i] : xi[i], sc, sh), 0.f);
-            yo[i] = v;
+            if (y16) yh[(size_t)c * HW + i] = (_Float16)v; else yo[i] = v;
             s += v;
             q += v * v;
             if (++it == 32) { ds += s; dq += q; s = 0.f; q = 0.f; it = 0; }
@@ -2650,7 +2652,7 @@ struct pp_net {
     float* zeros = nullptr;
     int num_cu = 256;
     int eff_prec = 0;   // the precision the launch plan is built for: ctx->precision, except 4 -> 3 when the concat buffer cannot be fp16
-    bool up16 = false;  // pp_set_precision 4 and every upsampler / the head on an io16 tiling: the concat buffer `up` holds fp16
+    bool up16 = false;  // pp_set_precision 4 with every layer on a 16-bit-tensor tiling: the level buffers and the concat buffer `up` hold fp16
     int w4_strips = -1; // PP_W4_STRIPS, read once at pp_create: -1 cost model, 0 never, 2 whenever whole main tiles exist (parity tests of the strip tiles)
 };
 
@@ -2683,18 +2685,20 @@ void conv_menu(std::vector<Variant>& m)
     m.push_back(make_variant<KS, STRIDE, 4, 2, 2, 2, 2, 2, KC, EPI>());  // 8x8 px, 64 rows
 }
 
-// S16 (pp_set_precision 4): the concat buffer is stored in fp16 -- the upsamplers write it (OUT16), the head reads it (IN16)
+// S16 (pp_set_precision 4): every activation tensor behind the first conv is stored in fp16 -- the upsamplers read fp16 block
+// outputs and write the fp16 concat buffer (io16 3), the head reads it (io16 1; its logits stay fp32)
 template <int PREC, bool S16 = false>
 void lp_menu(int kind, int up, std::vector<Variant>& menu)
 {
-    constexpr int HI = S16 ? 1 : 0, DO = S16 ? 2 : 0;
+    constexpr int HI = S16 ? 1 : 0, DO = S16 ? 3 : 0;
     if (kind == 2) { menu.push_back(make_g1<6, 4, EPI_HEAD, PREC, HI>()); menu.push_back(make_g1<3, 4, EPI_HEAD, PREC, HI>()); }
     else if (up == 1) { menu.push_back(make_g1<4, 4, EPI_PLAIN, PREC, DO>()); menu.push_back(make_g1<2, 4, EPI_PLAIN, PREC, DO>()); }
     else if (up == 2) { menu.push_back(make_g1<4, 4, EPI_UP2, PREC, DO>()); menu.push_back(make_g1<8, 4, EPI_UP2, PREC, DO>()); }
     else { menu.push_back(make_g1<4, 4, EPI_UP4, PREC, DO>()); menu.push_back(make_g1<8, 4, EPI_UP4, PREC, DO>()); }
 }
 
-void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true, int prec = 0)
+void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int cin = 0, bool roofline_layer = false, bool head9 = true, int prec = 0,
+                bool first_conv = false)
 {
     const bool g1ok = cin % 32 == 0; // gemm1x1 runs K in rings of 8 quad-steps without a tail
     // reduced-precision modes (pp_set_precision): the 1x1 contractions -- the three ConvTranspose(k = s) upsamplers and the
@@ -2707,7 +2711,9 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         return;
     }
     if (prec && kind == 0 && cin % 16 == 0) {
-        conv16_menu(stride, prec == 4 ? 3 : prec, menu); // fp16s: the convolutions are the fp16-operand kernels, their tensors stay fp32
+        // fp16s: the fp16-operand kernels on fp16 tensors; the first conv reads the fp32 PFN rows / canvas and writes fp16
+        if (prec == 4) conv16_menu(stride, 3, menu, first_conv ? 2 : 3);
+        else conv16_menu(stride, prec, menu);
         return;
     }
     if (kind == 2) {
@@ -3247,7 +3253,8 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     auto legal = [&](const Variant& v) {
         return variant_ok(v, rows_) && shape_ok(v, Hin, Win, Wout) && ((v.wino == 3) ? g1_lds(v, L.cin) : v.lds) <= (size_t)160 * 1024;
     };
-    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, eprec);
+    const bool first_conv = L.kind == 0 && L.stride == 2 && L.level == 0;
+    layer_menu(L.kind, L.stride, L.up, menu, L.cin, L.kind == 0 && L.stride == 1 && L.level == 0, ctx->cfg.num_anchor_per_loc == 9, eprec, first_conv);
     if (eprec) {
         // a shape none of the reduced-precision tilings takes (odd maps, Cin not a multiple of 16 / 32) runs its fp32 tilings:
         // pp_layer_tilings reports what really runs
@@ -3489,8 +3496,8 @@ int pp_net_commit(pp_ctx* ctx)
         const int H = ctx->H, W = ctx->W;
         float *tin = nullptr, *tout = nullptr;
         const bool can_tune = tune && (H % 4 == 0) && (W % 4 == 0);
-        // fp16 storage of the concat buffer needs every upsampler and the head on gemm1x1's 16-bit-tensor tilings: maps a multiple of
-        // 4 wide at all three levels and the 9-anchor head; otherwise mode 4 runs as mode 3 (fp16 operands, fp32 tensors)
+        // fp16 storage of the activations needs every conv on conv16's and every upsampler / the head on gemm1x1's 16-bit-tensor
+        // tilings: maps a multiple of 4 wide at all three levels and the 9-anchor head; otherwise mode 4 runs as mode 3 (fp32 tensors)
         net->up16 = ctx->precision == 4 && (W % 16 == 0) && ((H * W) % 64 == 0) && ctx->cfg.num_anchor_per_loc == 9;
         net->eff_prec = (ctx->precision == 4 && !net->up16) ? 3 : ctx->precision;
         if (can_tune) {
@@ -3518,8 +3525,9 @@ int pp_net_commit(pp_ctx* ctx)
         if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); tune_cache_save(); }
         if (net->up16)
             for (const Layer& L : net->layers)
-                if ((L.kind == 1 && L.var.io16 != 2) || (L.kind == 2 && L.var.io16 != 1))
-                    return pp_fail(ctx, PP_E_STATE, "fp16s: an upsampler or the head did not get a 16-bit-tensor tiling (PP_FORCE_VARIANT?)");
+                if ((L.kind == 1 && L.var.io16 != 3) || (L.kind == 2 && L.var.io16 != 1) ||
+                    (L.kind == 0 && L.var.io16 != ((L.stride == 2 && L.level == 0) ? 2 : 3)))
+                    return pp_fail(ctx, PP_E_STATE, "fp16s: a layer did not get a 16-bit-tensor tiling (PP_FORCE_VARIANT?)");
     }
     if (ctx->cfg.norm_kind == 1) {
         for (int b = 0; b < 3; ++b) {
@@ -3593,12 +3601,12 @@ double* stat_slot(pp_ctx* ctx, int site)
 }
 
 int launch_norm_relu(pp_ctx* ctx, const float* x, float* y, int C, int HW, const NormRef& pre, double* stat, hipStream_t stream,
-                     int B = 1, int x16 = 0)
+                     int B = 1, int x16 = 0, int y16 = 0)
 {
     int bx = pp_div_up(HW / 4, 256 * 4);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(norm_relu_stats, dim3(bx, C, B), dim3(256), 0, stream, x, y, C, HW, pre.mode, pre.acc, pre.scale,
-                       pre.shift, pre.inv_n, 1e-3f, stat, (size_t)C * HW, STAT_FS, x16);
+                       pre.shift, pre.inv_n, 1e-3f, stat, (size_t)C * HW, STAT_FS, x16, y16);
     PP_HIP(hipGetLastError());
     return 0;
 }
@@ -3632,7 +3640,7 @@ int pp_run_backbone(pp_ctx* ctx, const float* canvas, int nb, hipStream_t stream
         // y = relu(norm(Bf[0])) -> Bf[1] + stats(site 1) (the first Resnet2 unit's leading norm)
         if ((rc = pp_stage_mark(ctx, stream, PP_ST_NORM))) return rc;
         if ((rc = launch_norm_relu(ctx, Bf[0], Bf[1], c, (int)cnt, norm_ref(ctx, site_block(b, 0), c, 0, cnt),
-                                   stat_slot(ctx, site_block(b, 1)), stream, nb))) return rc;
+                                   stat_slot(ctx, site_block(b, 1)), stream, nb, net->up16 ? 1 : 0, net->up16 ? 1 : 0))) return rc;
         if ((rc = pp_stage_mark(ctx, stream, PP_ST_CONV))) return rc;
         float* cur = Bf[1];
         float* spare[3] = {Bf[0], Bf[2], Bf[3]};

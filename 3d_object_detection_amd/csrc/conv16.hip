@@ -44,6 +44,8 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -133,9 +135,15 @@ struct C16 {
 // SPARSE (stride 2 only): the first conv of the fused path -- the input is the pillar-index map of the BEV grid plus the PFN
 // rows (ConvP::pmap / feat) instead of a dense canvas; a tile whose halo patch holds no pillar skips its MFMA loop.  A twin
 // instantiation, so that the dense stride-2 layers do not carry its registers.
-template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC, bool SPARSE = false>
+// IO16 (pp_set_precision 4, "fp16s"): bit 0 = the input tensor is fp16, bit 1 = the output tensor (and the residual, which has the
+// output's layout) is fp16.  The arithmetic is the fp16-operand path either way: fp16 input is widened as it arrives and goes
+// through the same fp32 normalise / ReLU / round; outputs are rounded to fp16 behind the statistics.
+template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC, bool SPARSE = false, int IO16 = 0>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
 {
+    constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
+    static_assert(!(SPARSE && IN16), "the sparse first conv reads the fp32 PFN rows");
+    constexpr unsigned EBI = IN16 ? 2u : 4u, EBO = OUT16 ? 2u : 4u; // bytes per element of the input / output tensor
     using C = C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>;
     constexpr int NBUF = C::DB ? 2 : 1;
     constexpr int S = STRIDE;
@@ -197,9 +205,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         const int ox0 = tx * PW, oy0 = ty * PH;
         const int co0 = cb * C::BM;
         const int iy0 = oy0 * S - 1, qx0 = ox0 * S - 4;
-        const float* __restrict__ gin = p.in + (size_t)fr * p.in_fs;
+        const float* __restrict__ gin = IN16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(p.in) + (size_t)fr * p.in_fs) : p.in + (size_t)fr * p.in_fs;
         __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gin), 0, 0x7FFFFFFF, 0x00020000);
-        const unsigned plane_b = (unsigned)(in_plane * 4);
+        const unsigned plane_b = (unsigned)(in_plane * EBI);
         const int32_t* __restrict__ gmap = sparse ? p.pmap + (size_t)fr * p.pmap_fs : nullptr;
         const float* __restrict__ gfeat = sparse ? p.feat + (size_t)fr * p.feat_fs : nullptr;
         const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>(p.w) + (size_t)cb * (p.Cin / 16) * ((PREC == P16_BF16X3) ? 2 : 1) * C::W_UNITS;
@@ -267,7 +275,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                 // lane offset in a VGPR, the channel's plane offset in an SGPR: no address arithmetic on the VALU
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    xv[sl][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)goff[r] * 4u, (unsigned)(c0 + c) * plane_b, 0));
+                    if constexpr (IN16) { // 4 pixels = 8 bytes; widened to fp32 on arrival so that the staging code below is shared
+                        const f16x4 h_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rin, (unsigned)goff[r] * 2u, (unsigned)(c0 + c) * plane_b, 0));
+                        xv[sl][c] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};
+                    } else
+                        xv[sl][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)goff[r] * 4u, (unsigned)(c0 + c) * plane_b, 0));
             }
         };
         auto load_aff = [&](int step) __attribute__((always_inline)) {
@@ -435,8 +447,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         // wave instruction = 8 channels x 128 contiguous bytes.  The residual quads of block b + 2 are requested while block b
         // is transposed (the compiler must assume residual and output alias, so nothing is left for it to hoist).
         if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.out[0] = 1.f; if (!C::DB) __syncthreads(); continue; }
-        float* gout = p.out + (size_t)fr * p.out_fs;
-        const float* gres = p.res ? p.res + (size_t)fr * p.res_fs : nullptr;
+        float* gout = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out) + (size_t)fr * p.out_fs) : p.out + (size_t)fr * p.out_fs;
+        const float* gres = !p.res ? nullptr
+                            : OUT16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(p.res) + (size_t)fr * p.res_fs) : p.res + (size_t)fr * p.res_fs;
         // a frame's output is < 2 GB (checked on the host): lanes with nothing to store sit 2 GB out, where the descriptor drops them
         constexpr unsigned FAR = 0x80000000u;
         __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(gout, 0, 0x7FFFFFFF, 0x00020000);
@@ -450,9 +463,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
             const int py = pp / PW, px = pp - py * PW;
             const int oy = oy0 + py, ox = ox0 + px;
             const bool ok = oy < p.Hout && ox < p.Wout; // Wout % 4 == 0: inside or outside as a whole
-            qoff[j] = ok ? (unsigned)(((size_t)(co0 + wm * MT * 32 + tc) * out_plane + (size_t)oy * p.Wout + ox) * 4) : FAR;
+            qoff[j] = ok ? (unsigned)(((size_t)(co0 + wm * MT * 32 + tc) * out_plane + (size_t)oy * p.Wout + ox) * EBO) : FAR;
         }
-        const unsigned plane8 = (unsigned)(out_plane * 32); // bytes between channel octets
+        const unsigned plane8 = (unsigned)(out_plane * 8 * EBO); // bytes between channel octets
         constexpr int NB = MT * NT;
         constexpr int RD = C::DB ? 2 : 0;   // residual quads requested RD blocks ahead (two workgroups per CU: at the block itself, the partner covers the wait)
         f32x4 rres[RD + 1][4];
@@ -462,8 +475,13 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                 constexpr int i = b_ / NT, j = b_ % NT;
                 if (gres) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        rres[b_ % (RD + 1)][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
+                    for (int k = 0; k < 4; ++k) {
+                        if constexpr (OUT16) {
+                            const f16x4 h_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
+                            rres[b_ % (RD + 1)][k] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};
+                        } else
+                            rres[b_ % (RD + 1)][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
+                    }
                 }
             }
         };
@@ -483,7 +501,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
             for (int k = 0; k < 4; ++k) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * k + tc) * 36 + 4 * tq);
                 if (gres) v += rres[b_ % (RD + 1)][k];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, qoff[j], (unsigned)(i * 4 + k) * plane8, 0);
+                if constexpr (OUT16) {
+                    const u32x2 h_ = {pack2<P16_FP16>(v[0], v[1]), pack2<P16_FP16>(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(h_, ro, qoff[j], (unsigned)(i * 4 + k) * plane8, 0);
+                } else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, qoff[j], (unsigned)(i * 4 + k) * plane8, 0);
                 const float live = (qoff[j] != FAR) ? 1.f : 0.f;
                 ps[i][k] += live * ((v[0] + v[1]) + (v[2] + v[3]));
                 pq[i][k] += live * ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
@@ -531,27 +553,29 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
 #endif
 }
 
-template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC>
+template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC, int IO16 = 0>
 Variant make_c16()
 {
     using C = C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>;
     Variant v;
-    v.kern = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC>;
-    if constexpr (STRIDE == 2) v.kern2 = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC, true>;
+    v.kern = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC, false, IO16>;
+    if constexpr (STRIDE == 2 && !(IO16 & 1)) v.kern2 = conv16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC, true, IO16>; // the sparse first conv reads fp32 PFN rows
+    v.io16 = IO16;
     v.bm = C::BM; v.bmp = C::BM; v.pw = PW; v.ph = PH; v.kc = 16; v.threads = C::T;
     v.waves = 4 * OCC; v.pairs = MT * NT; // waves: per CU (the launcher sizes the persistent grid: waves * 64 / threads workgroups per CU)
     v.lds = C::LDS_BYTES;
     v.wino = 5;
     v.prec = PREC;
-    snprintf(v.name, sizeof(v.name), "c16 s%d p%d w%dx%d t%dx%d %dx%d o%d", STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC);
+    if (IO16) snprintf(v.name, sizeof(v.name), "c16 s%d p%d h%d w%dx%d t%dx%d %dx%d o%d", STRIDE, PREC, IO16, WM, WN, MT, NT, PW, PH, OCC);
+    else snprintf(v.name, sizeof(v.name), "c16 s%d p%d w%dx%d t%dx%d %dx%d o%d", STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC);
     return v;
 }
 
-template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC>
+template <int STRIDE, int PREC, int WM, int WN, int MT, int NT, int PW, int PH, int OCC, int IO16 = 0>
 void add_c16(std::vector<Variant>& m)
 {
     using C = C16<STRIDE, WM, WN, MT, NT, PW, PH, OCC>;
-    if constexpr (C::LDS_BYTES * C::WGS_PER_CU <= 160 * 1024) m.push_back(make_c16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC>());
+    if constexpr (C::LDS_BYTES * C::WGS_PER_CU <= 160 * 1024) m.push_back(make_c16<STRIDE, PREC, WM, WN, MT, NT, PW, PH, OCC, IO16>());
 }
 
 // Tile menu.  A tile is PW x PH output pixels = whole 32-pixel N-tiles in row-major order, so PW only has to divide the map:
@@ -560,36 +584,42 @@ void add_c16(std::vector<Variant>& m)
 // are 4x the output tile).  OCC 2 = two workgroups per CU (<= 256 registers, single-buffered LDS): the loads, the
 // normalise-and-round staging and the store tail of one workgroup run under the MFMAs of the other -- what the layers
 // that are bound by the memory pipe need; OCC 1 = one workgroup with the whole register file and double-buffered LDS.
-template <int STRIDE, int PREC>
+template <int STRIDE, int PREC, int IO16 = 0>
 void menu_for(std::vector<Variant>& m)
 {
     //              WM WN MT NT  PW  PH OCC    rows  pixels
     if constexpr (STRIDE == 1) {
-        add_c16<1, PREC, 2, 2, 1, 5, 40, 8, 2>(m);   //  64   320
-        add_c16<1, PREC, 2, 2, 1, 5, 80, 4, 2>(m);   //  64   320
-        add_c16<1, PREC, 2, 2, 1, 5, 20, 16, 2>(m);  //  64   320
-        add_c16<1, PREC, 4, 1, 1, 5, 20, 8, 2>(m);   // 128   160
-        add_c16<1, PREC, 4, 1, 1, 5, 40, 4, 2>(m);   // 128   160
-        add_c16<1, PREC, 4, 2, 1, 5, 40, 8, 2>(m);   // 128   320   eight waves in ONE workgroup: one weight image and one patch per 320 / 640
-        add_c16<1, PREC, 4, 2, 1, 5, 20, 16, 2>(m);  // 128   320   pixels instead of one per 160 / 320 (the 128- / 256-channel layers are bound by
-        add_c16<1, PREC, 2, 4, 1, 5, 80, 8, 2>(m);   //  64   640   L2 -> CU bytes per flop, profiles/r03_conv16_stamps.txt)
-        add_c16<1, PREC, 1, 4, 2, 5, 80, 8, 1>(m);   //  64   640
-        add_c16<1, PREC, 2, 2, 2, 5, 40, 8, 1>(m);   // 128   320
-        add_c16<1, PREC, 2, 2, 2, 5, 20, 16, 1>(m);  // 128   320
+        add_c16<1, PREC, 2, 2, 1, 5, 40, 8, 2, IO16>(m);   //  64   320
+        add_c16<1, PREC, 2, 2, 1, 5, 80, 4, 2, IO16>(m);   //  64   320
+        add_c16<1, PREC, 2, 2, 1, 5, 20, 16, 2, IO16>(m);  //  64   320
+        add_c16<1, PREC, 4, 1, 1, 5, 20, 8, 2, IO16>(m);   // 128   160
+        add_c16<1, PREC, 4, 1, 1, 5, 40, 4, 2, IO16>(m);   // 128   160
+        add_c16<1, PREC, 4, 2, 1, 5, 40, 8, 2, IO16>(m);   // 128   320   eight waves in ONE workgroup: one weight image and one patch per 320 / 640
+        add_c16<1, PREC, 4, 2, 1, 5, 20, 16, 2, IO16>(m);  // 128   320   pixels instead of one per 160 / 320 (the 128- / 256-channel layers are bound by
+        add_c16<1, PREC, 2, 4, 1, 5, 80, 8, 2, IO16>(m);   //  64   640   L2 -> CU bytes per flop, profiles/r03_conv16_stamps.txt)
+        add_c16<1, PREC, 1, 4, 2, 5, 80, 8, 1, IO16>(m);   //  64   640
+        add_c16<1, PREC, 2, 2, 2, 5, 40, 8, 1, IO16>(m);   // 128   320
+        add_c16<1, PREC, 2, 2, 2, 5, 20, 16, 1, IO16>(m);  // 128   320
     } else {
-        add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 2>(m);   //  64   320
-        add_c16<2, PREC, 2, 2, 1, 5, 20, 16, 2>(m);  //  64   320
-        add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 2>(m);   // 128   160
-        add_c16<2, PREC, 4, 2, 1, 5, 40, 8, 2>(m);   // 128   320   eight waves
-        add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 1>(m);   //  64   320
-        add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 1>(m);   // 128   160
+        add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 2, IO16>(m);   //  64   320
+        add_c16<2, PREC, 2, 2, 1, 5, 20, 16, 2, IO16>(m);  //  64   320
+        add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 2, IO16>(m);   // 128   160
+        add_c16<2, PREC, 4, 2, 1, 5, 40, 8, 2, IO16>(m);   // 128   320   eight waves
+        add_c16<2, PREC, 2, 2, 1, 5, 40, 8, 1, IO16>(m);   //  64   320
+        add_c16<2, PREC, 4, 1, 1, 5, 20, 8, 1, IO16>(m);   // 128   160
     }
 }
 
 } // namespace
 
-void conv16_menu(int stride, int prec, std::vector<Variant>& menu)
+void conv16_menu(int stride, int prec, std::vector<Variant>& menu, int io16)
 {
+    if (io16) { // pp_set_precision 4: fp16 operands with fp16 tensors (io16 3), the first conv with an fp16 output only (io16 2)
+        if (stride == 1) menu_for<1, P16_FP16, 3>(menu);
+        else if (io16 == 2) menu_for<2, P16_FP16, 2>(menu);
+        else menu_for<2, P16_FP16, 3>(menu);
+        return;
+    }
     if (stride == 1) {
         if (prec == P16_BF16X3) menu_for<1, P16_BF16X3>(menu);
         else if (prec == P16_BF16) menu_for<1, P16_BF16>(menu);

@@ -111,11 +111,11 @@ struct Variant { // one compiled tiling of conv_mfma
     int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
     int cin = 0;  // wino == 2: compiled for exactly this Cin
     int prec = 0; // wino == 3 / 5: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16, 3 fp16 operands
-    int io16 = 0; // wino == 3: bit 0 = the input tensor is fp16, bit 1 = the output tensor is (the concat buffer under pp_set_precision 4)
+    int io16 = 0; // wino == 3 / 5: bit 0 = the input tensor is fp16, bit 1 = the output tensor (and residual) is (pp_set_precision 4)
 };
 
 
 // conv16.hip: 16-bit operand 3x3 convolutions (fp16 / bf16 / split-bf16) -- menu entries for one layer shape and precision
-void conv16_menu(int stride, int prec, std::vector<Variant>& menu);
+void conv16_menu(int stride, int prec, std::vector<Variant>& menu, int io16 = 0);
 
 } // namespace ppc

@@ -398,9 +398,10 @@ def main():
         else:
             # 16-bit operands: the same layer is no longer bound by the matrix pipe.  Both floors are stated, the binding one
             # (the larger time) is the roofline: HBM with SURVEY 8(d)'s algorithmic bytes (input read once + output written
-            # once, fp32 activations: 2 * 4 * 64 * H * W per frame), MFMA with the executed flops at the 16-bit dense peak.
+            # once: 2 * 4 * 64 * H * W per frame with fp32 activations, half that under fp16s), MFMA with the executed flops at the 16-bit dense peak.
             nfr = min(NB, MAXB)
-            alg_bytes = 2.0 * 4 * 64 * eng.H * eng.W * nfr
+            elem = 2 if args.precision == "fp16s" else 4  # fp16s stores its activation tensors in fp16
+            alg_bytes = 2.0 * elem * 64 * eng.H * eng.W * nfr
             t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
             t_mfma = k_flops * ratio / (LP_MFMA_PEAK_TFLOPS * 1e12) * 1e3
             hbm_bound = t_hbm >= t_mfma
@@ -416,7 +417,8 @@ def main():
                                "note": "16-bit operand mode: floors of this layer per launch in `floors_ms`; the larger one is the bound"}
         if args.precision != "fp32":
             out["tagged"] = (f"reduced-precision deploy mode '{args.precision}': convolutions, upsamplers and head on 16-bit MFMA operands, fp32 accumulation, "
-                             "fp32 activations in HBM (SURVEY 8(f).4; the reference deploys TensorRT FP16 engines): NOT the headline -- "
+                             + ("fp16 activation tensors in HBM" if args.precision == "fp16s" else "fp32 activations in HBM") +
+                             " (SURVEY 8(f).4; the reference deploys TensorRT FP16 engines): NOT the headline -- "
                              "the headline is the fp32 line (dtype f32); tolerance table in DESIGN.md")
         if stub or (world > 1 and os.environ.get("PP_BENCH_BACKEND", "nccl") != "nccl"):
             out["rehearsal"] = "stub engine / ranks share devices, gather over gloo: not a measurement"

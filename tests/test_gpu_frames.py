@@ -307,8 +307,9 @@ def test_reduced_precision_modes(synth):
         eng.load_state_dict(sd)
         til = eng.layer_tilings()
         code = min(eng.PRECISIONS[mode], 3)  # fp16s: the fp16-operand tilings, with 16-bit-tensor variants (h1 / h2) around the concat buffer
-        if mode == "fp16s":
-            assert all((" h2 " in t["tiling"]) for t in til if t["kind"] == 1) and all((" h1 " in t["tiling"]) for t in til if t["kind"] == 2), til
+        if mode == "fp16s":  # every activation tensor behind the first conv in fp16: convs h3 (the first one h2: fp32 in), upsamplers h3, head h1
+            assert all((" h3 " in t["tiling"]) for t in til if t["kind"] == 1) and all((" h1 " in t["tiling"]) for t in til if t["kind"] == 2), til
+            assert all((" h2 " if (t["stride"] == 2 and t["level"] == 0) else " h3 ") in t["tiling"] for t in til if t["kind"] == 0), til
         for t in til:  # what really runs: every conv on conv16, every 1x1 contraction on the reduced-precision gemm1x1
             name = t["tiling"]
             if mode == "fp32":
@@ -323,6 +324,18 @@ def test_reduced_precision_modes(synth):
         out[mode] = (gl, det[:cnt[0]].cpu().numpy(), cnt)
         if mode in ("fp32", "bf16x3"):
             compare_frame(r, gl, out[mode][1], cnt, 0, f"nuscene precision {mode}")
+        if mode == "fp16s":
+            # the stand-alone stage entry points (dense canvas -> pp_backbone -> fp32 rpn tensor -> pp_head, which rounds it back into the fp16
+            # concat buffer) against the fused sparse path of the same mode
+            v, c, n, num = eng.voxelize(cloud)
+            rpn = eng.backbone(eng.scatter(eng.pfn(v, c, n, num), c, num))
+            cls2, box2, dr2 = eng.head(rpn)
+            dev2 = max(float(np.abs(cls2.cpu().numpy().reshape(-1) - gl["cls"]).max()), float(np.abs(box2.cpu().numpy().reshape(-1, 7) - gl["box"]).max()),
+                       float(np.abs(dr2.cpu().numpy().reshape(-1, 2) - gl["dir"]).max()))
+            line = f"[precision] fp16s: stand-alone pp_backbone + pp_head vs the fused path: max logit deviation {dev2:.2e}"
+            print(line)
+            report(line)
+            assert dev2 <= 2e-2, dev2
     f32 = out["fp32"]
     for mode, (bar, share) in PRECISION_BARS.items():
         dev = {k: float(np.abs(out[mode][0][k] - f32[0][k]).max()) for k in ("cls", "box", "dir")}

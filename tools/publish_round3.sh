@@ -9,7 +9,7 @@ cp $O/prof.json $P/r03_bench_default_profiled.json
 cp $O/hbm_traffic.json $P/r03_hbm_traffic.json
 { echo "== SQ waits (rocprofv3 --pmc, bench.py default, wino kernels)"; cat $O/pmc_sq_waits.txt; echo "== instruction mix"; cat $O/pmc_inst_mix.txt; echo "== GRBM_GUI_ACTIVE (clock = value / 8 XCDs / duration)"; cat $O/pmc_clock.txt; } > $P/r03_pmc_wino4.txt
 cp $O/parity_report.txt $P/r03_parity_report.txt
-for M in fp16 bf16 bf16x3; do cp $O/tagged_$M.json $P/r03_bench_tagged_$M.json; done
+for M in fp16 fp16s bf16 bf16x3; do cp $O/tagged_$M.json $P/r03_bench_tagged_$M.json; done
 cp $O/x_fp16/kernel_summary.txt $P/r03_fp16_kernel_summary.txt
 cp $(ls -t $O/x_fp16/prof/*/*kernel_stats.csv | head -1) $P/r03_fp16_kernel_stats.csv
 cp $O/pmc_fp16.log $P/r03_pmc_conv16_fp16.txt

@@ -13,7 +13,7 @@ grep -E "^\.*\[(rotated iou)" $O/gpu_tests.log | sed 's/^\.*//' >> $O/parity_rep
 tail -1 $O/gpu_tests.log
 timeout -k 10 900 bash tools/profile_round3.sh > $O/profile.log 2>&1
 tail -2 $O/profile.log | cut -c1-300
-for M in bf16x3 bf16 fp16; do
+for M in bf16x3 bf16 fp16 fp16s; do
   timeout -k 10 300 python bench.py --precision $M --no-cpu-baseline > $O/tagged_$M.json 2> $O/tagged_$M.err
   echo "tagged $M: $(python tools/print_bench.py $O/tagged_$M.json | head -1)"
 done
