@@ -43,7 +43,7 @@ class PointPillars:
         return self
 
     def precision(self, mode):
-        """ "fp32" | "bf16x3" (split-bf16: fp32-equivalent on the bf16 MFMAs) | "fp16" | "bf16"."""
+        """ "fp32" | "bf16x3" (split-bf16: fp32-equivalent on the bf16 MFMAs) | "fp16" | "bf16" | "fp16s" (fp16 operands and fp16 tensors)."""
         self._eng.set_precision(mode)
         return self
 
