@@ -2244,28 +2244,40 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             const uint2* wl2 = reinterpret_cast<const uint2*>(wl);
             const int nkb = K / 16;
             f32x4 q0[4], q1[4];
-            // fp16 input: a lane's 4 pixels of a channel are 8 bytes; they are widened to fp32 as they arrive, so the block code is shared
-#define G1_LP_LOAD(Q, KB) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                     \
-        if constexpr (IN16) {                                                                                               \
-            const f16x4_t h_ = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_raw_buffer_load_b64(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
-            Q[t] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};                                            \
-        } else Q[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
+            uint2 g0[4], g1[4]; // fp16 input: a lane's 4 pixels of a channel are 8 bytes, kept as they arrive
+#define G1_LP_LOAD(Q, G, KB) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                  \
+        if constexpr (IN16) G[t] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
+        else Q[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bvq, (unsigned)((KB) * 16 + t) * cstep, 0)); \
     }
-#define G1_LP_BLOCK(Q, KB)                                                                       \
+            // RAW (compile-time twin of the loop, chosen per launch: the upsamplers read raw block outputs, the fused head normalises):
+            // no (scale, shift) reads and no fma / max; an fp16 raw input is already the operand's arithmetic -- channel pairs of
+            // pixel j are picked out of the (pixel-pair) words with two v_perm_b32, no conversion at all
+#define G1_LP_BLOCK(Q, G, KB, RAW)                                                               \
     {                                                                                            \
         f32x4 sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = (f32x4){0.f, 0.f, 0.f, 0.f};              \
-        if (p.pre != PRE_RAW) { sc4 = *reinterpret_cast<const f32x4*>(scl + (KB) * 16 + kq * 4); sh4 = *reinterpret_cast<const f32x4*>(shl + (KB) * 16 + kq * 4); } \
+        if constexpr (!(RAW)) { sc4 = *reinterpret_cast<const f32x4*>(scl + (KB) * 16 + kq * 4); sh4 = *reinterpret_cast<const f32x4*>(shl + (KB) * 16 + kq * 4); } \
         s16x4 bh[NT], bl[NT];                                                                    \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
-            float v_[4];                                                                         \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t) v_[t] = (p.pre != PRE_RAW) ? fmaxf(fmaf(Q[t][j], sc4[t], sh4[t]), 0.f) : Q[t][j]; \
-            const unsigned h0 = (PREC == 3) ? pk_f16(v_[0], v_[1]) : pk_bf16(v_[0], v_[1]);      \
-            const unsigned h1 = (PREC == 3) ? pk_f16(v_[2], v_[3]) : pk_bf16(v_[2], v_[3]);      \
-            bh[j] = __builtin_bit_cast(s16x4, (uint2){h0, h1});                                  \
-            if constexpr (PREC == 1) {                                                           \
-                const float l0 = v_[0] - __uint_as_float(h0 << 16), l1 = v_[1] - __uint_as_float(h0 & 0xFFFF0000u); \
-                const float l2 = v_[2] - __uint_as_float(h1 << 16), l3 = v_[3] - __uint_as_float(h1 & 0xFFFF0000u); \
-                bl[j] = __builtin_bit_cast(s16x4, (uint2){pk_bf16(l0, l1), pk_bf16(l2, l3)});    \
+            if constexpr (IN16 && (RAW)) {                                                       \
+                const unsigned sel_ = (j & 1) ? 0x07060302u : 0x05040100u;                       \
+                const unsigned h0 = __builtin_amdgcn_perm((j & 2) ? G[1].y : G[1].x, (j & 2) ? G[0].y : G[0].x, sel_); \
+                const unsigned h1 = __builtin_amdgcn_perm((j & 2) ? G[3].y : G[3].x, (j & 2) ? G[2].y : G[2].x, sel_); \
+                bh[j] = __builtin_bit_cast(s16x4, (uint2){h0, h1});                              \
+            } else {                                                                             \
+                float v_[4];                                                                     \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                  \
+                    float x_;                                                                    \
+                    if constexpr (IN16) x_ = (float)__builtin_bit_cast(f16x4_t, G[t])[j]; else x_ = Q[t][j]; \
+                    v_[t] = (RAW) ? x_ : fmaxf(fmaf(x_, sc4[t], sh4[t]), 0.f);                   \
+                }                                                                                \
+                const unsigned h0 = (PREC == 3) ? pk_f16(v_[0], v_[1]) : pk_bf16(v_[0], v_[1]);  \
+                const unsigned h1 = (PREC == 3) ? pk_f16(v_[2], v_[3]) : pk_bf16(v_[2], v_[3]);  \
+                bh[j] = __builtin_bit_cast(s16x4, (uint2){h0, h1});                              \
+                if constexpr (PREC == 1) {                                                       \
+                    const float l0 = v_[0] - __uint_as_float(h0 << 16), l1 = v_[1] - __uint_as_float(h0 & 0xFFFF0000u); \
+                    const float l2 = v_[2] - __uint_as_float(h1 << 16), l3 = v_[3] - __uint_as_float(h1 & 0xFFFF0000u); \
+                    bl[j] = __builtin_bit_cast(s16x4, (uint2){pk_bf16(l0, l1), pk_bf16(l2, l3)}); \
+                }                                                                                \
             }                                                                                    \
         }                                                                                        \
         _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
@@ -2281,15 +2293,18 @@ __global__ void __launch_bounds__(512, 2) gemm1x1(const ConvP p)
             }                                                                                    \
         }                                                                                        \
     }
+#define G1_LP_LOOP(RAW)                                                                          \
+    G1_LP_LOAD(q0, g0, 0)                                                                        \
+    for (int kb = 0; kb < nkb; kb += 2) { /* K % 32 == 0: whole pairs of blocks */               \
+        G1_LP_LOAD(q1, g1, kb + 1)                                                               \
+        G1_LP_BLOCK(q0, g0, kb, RAW)                                                             \
+        if (kb + 2 < nkb) G1_LP_LOAD(q0, g0, kb + 2)                                             \
+        G1_LP_BLOCK(q1, g1, kb + 1, RAW)                                                         \
+    }
             __builtin_amdgcn_s_setprio(0);
-            G1_LP_LOAD(q0, 0)
-            for (int kb = 0; kb < nkb; kb += 2) { // K % 32 == 0: whole pairs of blocks
-                G1_LP_LOAD(q1, kb + 1)
-                G1_LP_BLOCK(q0, kb)
-                if (kb + 2 < nkb) G1_LP_LOAD(q0, kb + 2)
-                G1_LP_BLOCK(q1, kb + 1)
-            }
+            if (p.pre == PRE_RAW) { G1_LP_LOOP(true) } else { G1_LP_LOOP(false) }
             __builtin_amdgcn_s_setprio(1);
+#undef G1_LP_LOOP
 #undef G1_LP_LOAD
 #undef G1_LP_BLOCK
         }

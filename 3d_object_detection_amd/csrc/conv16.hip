@@ -126,8 +126,13 @@ struct C16 {
     static constexpr int SCR_FLOATS = NW * 32 * 36; // wave-private transpose tiles of the epilogue
     // OCC 2: the transpose tiles alias the (idle) operand buffers; a barrier closes every item
     static_assert(DB || (size_t)(X_UNITS + W_UNITS) * 16 >= (size_t)SCR_FLOATS * 4, "transpose tiles must fit the operand buffers");
+    // single-buffered patch, but TWO weight images where the CU's LDS allows it: the weights of step s+1 are requested before the
+    // MFMA loop of step s and written behind it, ahead of the barrier (the image a workgroup re-reads per step is the larger half of
+    // what it stages, and fetched behind the barrier its latency and its trip through the memory pipe were exposed)
+    static constexpr bool WDB = !DB && ((size_t)(X_UNITS + 2 * W_UNITS) * 16 + RED_FLOATS * 4) * WGS_PER_CU <= 160 * 1024;
+    static constexpr int NWBUF = (DB || WDB) ? 2 : 1;
     static constexpr size_t LDS_BYTES = DB ? (size_t)(2 * (X_UNITS + W_UNITS)) * 16 + (RED_FLOATS + SCR_FLOATS) * 4
-                                           : (size_t)(X_UNITS + W_UNITS) * 16 + RED_FLOATS * 4;
+                                           : (size_t)(X_UNITS + NWBUF * W_UNITS) * 16 + RED_FLOATS * 4;
     static_assert(PW % 4 == 0, "the epilogue stores pixel quads");
 };
 
@@ -150,8 +155,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
     constexpr int PASSES = (PREC == P16_BF16X3) ? 3 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xl = reinterpret_cast<u32x4*>(smem_raw);               // [NBUF][X_UNITS]
-    u32x4* wl = xl + NBUF * C::X_UNITS;                            // [NBUF][W_UNITS]
-    float* red = reinterpret_cast<float*>(wl + NBUF * C::W_UNITS); // [WN][BM][2]
+    u32x4* wl = xl + NBUF * C::X_UNITS;                            // [NWBUF][W_UNITS]
+    float* red = reinterpret_cast<float*>(wl + C::NWBUF * C::W_UNITS); // [WN][BM][2]
     float* scr_all = C::DB ? red + C::RED_FLOATS : reinterpret_cast<float*>(smem_raw); // [4 waves][32][36] epilogue transpose tiles
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         auto need_w = [&](int step) __attribute__((always_inline)) { return !(C::DB && PASSES == 3) || (step % 3) != 2; };
         auto xbuf_of = [&](int step) __attribute__((always_inline)) { return !C::DB ? 0 : PASSES == 3 ? ((step % 3) == 2 ? 1 : 0) : (step & 1); };
         auto wbuf_of = [&](int step) __attribute__((always_inline)) {
-            if (!C::DB) return 0;
+            if (!C::DB) return C::WDB ? (step & 1) : 0;
             if (PASSES != 3) return step & 1;
             const int c = step / 3, ps = step - 3 * c;
             return ps == 1 ? 1 - (c & 1) : (c & 1);
@@ -365,8 +370,10 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         // single-buffered: rounds 1.. of the patch and the weight image, fetched and written one after the other
         auto stage_rest = [&](int step) __attribute__((always_inline)) {
             pp_steps<1, C::XR>([&](auto R) __attribute__((always_inline)) { issue_x(step, R, I0{}); commit_x(step, 0, R, I0{}); });
-            issue_w(step);
-            commit_w(0);
+            if constexpr (!C::WDB) {
+                issue_w(step);
+                commit_w(0);
+            }
         };
 
         if (any) {
@@ -392,6 +399,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                     } else {
                         issue_x(step + 1, I0{}, I0{});
                         load_aff(step + 1);
+                        if constexpr (C::WDB) issue_w(step + 1);
                     }
                 }
                 C16_T(1)
@@ -427,6 +435,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                     __syncthreads();
                     C16_T(5)
                 } else {
+                    if constexpr (C::WDB)
+                        if (stage && !(p.dbg & 128)) commit_w(wbuf_of(step + 1)); // the other image: nobody reads it in this step
                     __syncthreads(); // every wave is done reading the operands of this step
                     C16_T(3)
                     if (stage) {

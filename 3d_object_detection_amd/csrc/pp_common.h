@@ -33,7 +33,7 @@ struct pp_post_frame {
     int32_t *counters, *hist, *dirl;
     float *boxes, *nbox;
 };
-#define PP_GROUP 16 // frames per batched launch of the integer stages (kernel-argument table size)
+#define PP_GROUP 32 // frames per batched launch of the integer stages (kernel-argument table size: 384 B of the 4 KB)
 struct pp_in_group {
     const float* pts[PP_GROUP];
     int32_t n[PP_GROUP];
