@@ -280,9 +280,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                 // lane offset in a VGPR, the channel's plane offset in an SGPR: no address arithmetic on the VALU
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if constexpr (IN16) { // 4 pixels = 8 bytes; widened to fp32 on arrival so that the staging code below is shared
-                        const f16x4 h_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rin, (unsigned)goff[r] * 2u, (unsigned)(c0 + c) * plane_b, 0));
-                        xv[sl][c] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};
+                    if constexpr (IN16) { // 4 pixels = 8 bytes, kept as they arrive (components 0, 1) and widened at the commit: a conversion
+                                          // here would sit in front of the MFMA loop and make the wave wait for the loads it has just issued
+                        const f32x2 h_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, (unsigned)goff[r] * 2u, (unsigned)(c0 + c) * plane_b, 0));
+                        xv[sl][c][0] = h_[0];
+                        xv[sl][c][1] = h_[1];
                     } else
                         xv[sl][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (unsigned)goff[r] * 4u, (unsigned)(c0 + c) * plane_b, 0));
             }
@@ -317,7 +319,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
                 float v[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    float x = sparse ? xv[sl][2 * e + (c >> 2)][c & 3] : xv[sl][c][e];
+                    float x;
+                    if constexpr (IN16) x = (float)__builtin_bit_cast(f16x4, (f32x2){xv[sl][c][0], xv[sl][c][1]})[e];
+                    else x = sparse ? xv[sl][2 * e + (c >> 2)][c & 3] : xv[sl][c][e];
                     if (p.pre != PRE_RAW) x = fmaxf(fmaf(x, sc8[c], sh8[c]), 0.f);
                     const bool live = sparse ? (pid[r][e] >= 0) : ok;
                     v[c] = live ? x : 0.f; // zero padding / empty cell, in the normalised domain
@@ -477,7 +481,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
         }
         const unsigned plane8 = (unsigned)(out_plane * 8 * EBO); // bytes between channel octets
         constexpr int NB = MT * NT;
-        constexpr int RD = C::DB ? 2 : 0;   // residual quads requested RD blocks ahead (two workgroups per CU: at the block itself, the partner covers the wait)
+        // residual quads requested RD blocks ahead (two workgroups per CU: at the block itself, the partner covers the wait -- or one
+        // block ahead when the residual is fp16: kept as loaded, a ring slot is 8 registers instead of 16)
+        constexpr int RD = C::DB ? 2 : OUT16 ? 1 : 0;
         f32x4 rres[RD + 1][4];
         auto req_res = [&](auto B) __attribute__((always_inline)) {
             constexpr int b_ = decltype(B)::value;
@@ -487,8 +493,9 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if constexpr (OUT16) {
-                            const f16x4 h_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
-                            rres[b_ % (RD + 1)][k] = (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};
+                            const f32x2 h_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
+                            rres[b_ % (RD + 1)][k][0] = h_[0]; // widened where it is added
+                            rres[b_ % (RD + 1)][k][1] = h_[1];
                         } else
                             rres[b_ % (RD + 1)][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, qoff[j], (unsigned)(i * 4 + k) * plane8, 0));
                     }
@@ -510,7 +517,13 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv16(const ConvP p)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * k + tc) * 36 + 4 * tq);
-                if (gres) v += rres[b_ % (RD + 1)][k];
+                if (gres) {
+                    if constexpr (OUT16) {
+                        const f16x4 h_ = __builtin_bit_cast(f16x4, (f32x2){rres[b_ % (RD + 1)][k][0], rres[b_ % (RD + 1)][k][1]});
+                        v += (f32x4){(float)h_[0], (float)h_[1], (float)h_[2], (float)h_[3]};
+                    } else
+                        v += rres[b_ % (RD + 1)][k];
+                }
                 if constexpr (OUT16) {
                     const u32x2 h_ = {pack2<P16_FP16>(v[0], v[1]), pack2<P16_FP16>(v[2], v[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(h_, ro, qoff[j], (unsigned)(i * 4 + k) * plane8, 0);

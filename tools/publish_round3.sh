@@ -13,6 +13,9 @@ for M in fp16 fp16s bf16 bf16x3; do cp $O/tagged_$M.json $P/r03_bench_tagged_$M.
 cp $O/x_fp16/kernel_summary.txt $P/r03_fp16_kernel_summary.txt
 cp $(ls -t $O/x_fp16/prof/*/*kernel_stats.csv | head -1) $P/r03_fp16_kernel_stats.csv
 cp $O/pmc_fp16.log $P/r03_pmc_conv16_fp16.txt
+cp $O/y_fp16s/kernel_summary.txt $P/r03_fp16s_kernel_summary.txt
+cp $O/pmc_g1_fp16s.log $P/r03_pmc_gemm1x1_fp16s.txt
+cp $O/b1_prof.log $P/r03_batch1_kernel_summary.txt
 cp $O/cfg_nuscene.json $P/r03_bench_config_nuscene.json
 cp $O/cfg_ntusl_10cm.json $P/r03_bench_config_ntusl_10cm.json
 ls -la $P | grep r03

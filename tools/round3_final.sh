@@ -19,6 +19,9 @@ for M in bf16x3 bf16 fp16 fp16s; do
 done
 timeout -k 10 400 bash tools/prof_prec.sh fp16 r03/x > $O/prof_fp16.log 2>&1 || true
 timeout -k 10 400 bash tools/pmc_prec.sh fp16 r03/x > $O/pmc_fp16.log 2>&1 || true
+timeout -k 10 400 bash tools/prof_prec.sh fp16s r03/y > $O/prof_fp16s.log 2>&1 || true
+timeout -k 10 400 bash tools/pmc_g1.sh fp16s r03/y > $O/pmc_g1_fp16s.log 2>&1 || true
+timeout -k 10 200 bash tools/b1_prof.sh r03/b1 > $O/b1_prof.log 2>&1 || true
 timeout -k 10 200 python bench.py --config nuscene --no-cpu-baseline --no-extras > $O/cfg_nuscene.json 2> $O/cfg_nuscene.err
 timeout -k 10 300 python bench.py --config ntusl_10cm --batch 16 --no-cpu-baseline --no-extras > $O/cfg_ntusl_10cm.json 2> $O/cfg_ntusl_10cm.err
 for f in cfg_nuscene cfg_ntusl_10cm; do echo "$f: $(python tools/print_bench.py $O/$f.json | head -1)"; done
