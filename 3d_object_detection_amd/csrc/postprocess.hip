@@ -447,8 +447,12 @@ __device__ __forceinline__ void nms_mask_body(const int c, const float* __restri
 // Greedy sweep (nms_postprocess, nms.py:85-102) for one class by ONE wavefront on the transposed mask.
 // Lane j keeps the suppression word of tile j.  Per tile t: every lane loads its column's words for tile t
 // (diagonal) and the later tiles need only one load + one ballot each.  Returns #kept (<= max_keep).
-__device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int K, int cb, int max_keep, int* __restrict__ keep)
+__device__ __forceinline__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n_, int K_, int cb, int max_keep_, int* __restrict__ keep)
 {
+    // one wave, wave-uniform control: as an out-of-line function its arguments arrived in VGPRs and the whole sweep -- loop control,
+    // find-first, the 64-bit masks -- ran as divergent VALU code under exec masking; inlined, with the scalars pinned, it runs on the
+    // scalar unit (and the caller's address spaces reach its loads and stores)
+    const int n = __builtin_amdgcn_readfirstlane(n_), K = __builtin_amdgcn_readfirstlane(K_), max_keep = __builtin_amdgcn_readfirstlane(max_keep_);
     // maskT[t * K + col]: all loads of a step are 512 contiguous bytes.  The words of row tile t + 1 (diagonal + the next AH column
     // tiles) are requested BEFORE the serial sweep of tile t: nothing in them depends on the sweep, and fetched in place they were a
     // global-memory round trip per tile on the one wave that does the work (16 tiles of a 1000-box class: ~40 of the 59 us).
@@ -457,14 +461,20 @@ __device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int K,
     uint64_t remv = 0ull; // lane j: columns of tile j already suppressed
     int nk = 0;
     const int tiles = (n + 63) >> 6;
+    if (n <= 0) return 0;
+    // branch-free: clamped addresses + selects.  (Written as `cond ? row[i] : 0` every load sat in a basic block of its own and the
+    // compiler, unable to count what is in flight, waited for vmcnt(0) in front of every use.)
     auto fetch = [&](int t, uint64_t (&w)[AH], uint64_t& diag) __attribute__((always_inline)) {
-        const uint64_t* row = maskT + (size_t)t * K;
+        const bool live = t < tiles;
+        const uint64_t* row = maskT + (size_t)(live ? t : tiles - 1) * K;
         const int i = t * 64 + lane;
-        diag = (t < tiles && i < n) ? row[i] : 0ull; // rows of tile t suppressing column i
+        const uint64_t d = row[i < n ? i : n - 1];
+        diag = (live && i < n) ? d : 0ull; // rows of tile t suppressing column i
 #pragma unroll
         for (int u = 0; u < AH; ++u) {
             const int cidx = (t + 1 + u) * 64 + lane;
-            w[u] = (t + 1 + u < tiles && cidx < n) ? row[cidx] : 0ull;
+            const uint64_t x = row[cidx < n ? cidx : n - 1];
+            w[u] = (live && t + 1 + u < tiles && cidx < n) ? x : 0ull;
         }
     };
     uint64_t wc[AH], diag;
@@ -473,7 +483,8 @@ __device__ int nms_greedy_wave(const uint64_t* __restrict__ maskT, int n, int K,
         uint64_t wn[AH], dn;
         fetch(t + 1, wn, dn);
         const uint64_t* row = maskT + (size_t)t * K;
-        const uint64_t rt = __shfl(remv, t);
+        const uint64_t rtv = __shfl(remv, t);
+        const uint64_t rt = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rtv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rtv);
         const int valid = min(64, n - t * 64);
         uint64_t alive = ~rt & (valid == 64 ? ~0ull : ((1ull << valid) - 1ull));
         uint64_t kept = 0ull;
@@ -520,13 +531,17 @@ __device__ __forceinline__ void nms_reduce_body(pp_config cfg, const uint64_t* _
 {
     __shared__ int s_cnt[PP_MAX_CLASSES];
     __shared__ int s_out[PP_MAX_CLASSES][MAXK > 1024 ? 1024 : MAXK]; // kept rows surviving the range mask (post_max <= 1024)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ncls = cfg.num_classes;
     if (wave < ncls) {
         const int c = wave;
-        const int n = counters[c * 8 + 3];
-        int* keep = keep_ws + (size_t)c * K;
-        const int nk = nms_greedy_wave(mask + (size_t)c * K * cb, n, K, cb, cfg.nms_post_max, keep);
+        const int n = __builtin_amdgcn_readfirstlane(counters[c * 8 + 3]);
+        // the kept list goes to LDS (compacted in place below): a global store per kept box inside the sweep put an unknown number of
+        // stores into the vmcnt queue, so every tile's fold waited for vmcnt(0) -- the NEXT tile's words included (one memory round
+        // trip per tile on the one wave that does the work)
+        int* keep = s_out[c];
+        (void)keep_ws;
+        const int nk = nms_greedy_wave(mask + (size_t)c * K * cb, n, K, cb, cfg.nms_post_max, keep); // <= 1024 (pp_create)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // direction flip + range mask (quirk: dims vs upper limits, inference.py:107-109), stable compaction
@@ -541,8 +556,9 @@ __device__ __forceinline__ void nms_reduce_body(pp_config cfg, const uint64_t* _
                 const bool mx = ((double)b[3] < cfg.center_limit[3]) || ((double)b[4] < cfg.center_limit[4]) || ((double)b[5] < cfg.center_limit[5]);
                 ok = mn && mx;
             }
+            const int kv = k < nk ? keep[k] : 0; // every lane reads before any lane writes: positions no + prefix <= k0 + lane
             const unsigned long long bal = __ballot(ok);
-            if (ok) s_out[c][no + __popcll(bal & ((1ull << lane) - 1ull))] = keep[k];
+            if (ok) s_out[c][no + __popcll(bal & ((1ull << lane) - 1ull))] = kv;
             no += __popcll(bal);
         }
         if (lane == 0) s_cnt[c] = no;
@@ -792,9 +808,9 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
 void pp_post_fill_table(pp_ctx* ctx, int slot, pp_post_frame* f)
 {
     const pp_post* P = (const pp_post*)ctx->slot[slot].post;
-    f->cand = P->cand; f->shortl = P->shortl; f->sel = P->sel; f->nmask = P->nmask;
-    f->counters = P->counters; f->hist = P->hist; f->dirl = P->dirl;
-    f->boxes = P->boxes; f->nbox = P->nbox;
+    PP_SET(f->cand, P->cand); PP_SET(f->shortl, P->shortl); PP_SET(f->sel, P->sel); PP_SET(f->nmask, P->nmask);
+    PP_SET(f->counters, P->counters); PP_SET(f->hist, P->hist); PP_SET(f->dirl, P->dirl);
+    PP_SET(f->boxes, P->boxes); PP_SET(f->nbox, P->nbox);
 }
 
 // post-processing of frames b0 .. b0+g-1 as one launch per stage (blockIdx.z = frame)

@@ -176,17 +176,17 @@ int pp_build_tables(pp_ctx* ctx)
     for (int b = 0; b < ctx->max_batch; ++b) {
         const pp_slot& S = ctx->slot[b];
         pp_pre_frame& f = pre[b];
-        f.pt_cell = S.pt_cell; f.cell_first = S.cell_first; f.wave_cnt = S.wave_cnt; f.pt_rank = S.pt_rank;
-        f.slots = S.slots; f.scalars = S.vox_scalars; f.occ = S.occ;
-        f.voxels = ctx->f_voxels + b * vs;
-        f.coors = ctx->f_coors + b * mv * 3;
-        f.npts = ctx->f_npts + b * mv;
-        f.num = ctx->f_num + b * 4;
-        f.mask = ctx->f_mask + b * A;
-        f.feat = ctx->f_feat + b * mv * 64;
-        f.pmap = ctx->f_pmap + b * cells;
+        PP_SET(f.pt_cell, S.pt_cell); PP_SET(f.cell_first, S.cell_first); PP_SET(f.wave_cnt, S.wave_cnt); PP_SET(f.pt_rank, S.pt_rank);
+        PP_SET(f.slots, S.slots); PP_SET(f.scalars, S.vox_scalars); PP_SET(f.occ, S.occ);
+        PP_SET(f.voxels, ctx->f_voxels + b * vs);
+        PP_SET(f.coors, ctx->f_coors + b * mv * 3);
+        PP_SET(f.npts, ctx->f_npts + b * mv);
+        PP_SET(f.num, ctx->f_num + b * 4);
+        PP_SET(f.mask, ctx->f_mask + b * A);
+        PP_SET(f.feat, ctx->f_feat + b * mv * 64);
+        PP_SET(f.pmap, ctx->f_pmap + b * cells);
         pp_post_frame& q = post[b];
-        q.cls = ctx->f_cls + b * A; q.box = ctx->f_box + b * A * 7; q.dir = ctx->f_dir + b * A * 2; q.mask = f.mask;
+        PP_SET(q.cls, ctx->f_cls + b * A); PP_SET(q.box, ctx->f_box + b * A * 7); PP_SET(q.dir, ctx->f_dir + b * A * 2); PP_SET(q.mask, ctx->f_mask + b * A);
         pp_post_fill_table(ctx, b, &q);
     }
     PP_HIP(hipMemcpy(ctx->d_pre, pre.data(), sizeof(pp_pre_frame) * pre.size(), hipMemcpyHostToDevice));

@@ -18,20 +18,29 @@
 // ---- frame tables of the batched integer stages (pp_infer_batch) ---------------------------------
 // The voxeliser / mask / PFN / post-processing kernels of a batch run as ONE launch per stage with
 // blockIdx.z = frame; each frame's buffers are looked up in a device-resident table built once.
+// Device side: the table entries are typed as GLOBAL pointers.  A pointer loaded from memory carries no address space, so every
+// access through these tables used to be flat_load / flat_store (both wait counters, conservative s_waitcnt 0 around each); typed,
+// the inlined stage bodies get global_load / global_store.  Same 8-byte layout on the host, which fills the tables.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PP_GP __attribute__((address_space(1)))
+#else
+#define PP_GP
+#endif
+#define PP_SET(dst, src) dst = (decltype(dst))(src) // host-side fill (the host functions are parsed in the device pass as well)
 struct pp_pre_frame {
-    int32_t *pt_cell, *cell_first, *wave_cnt, *pt_rank, *slots, *scalars, *occ;
-    float* voxels;
-    int32_t *coors, *npts, *num;
-    uint8_t* mask;
-    float* feat;
-    int32_t* pmap;
+    int32_t PP_GP *pt_cell, *cell_first, *wave_cnt, *pt_rank, *slots, *scalars, *occ;
+    float PP_GP* voxels;
+    int32_t PP_GP *coors, *npts, *num;
+    uint8_t PP_GP* mask;
+    float PP_GP* feat;
+    int32_t PP_GP* pmap;
 };
 struct pp_post_frame {
-    const float *cls, *box, *dir;
-    const uint8_t* mask;
-    uint64_t *cand, *shortl, *sel, *nmask;
-    int32_t *counters, *hist, *dirl;
-    float *boxes, *nbox;
+    const float PP_GP *cls, *box, *dir;
+    const uint8_t PP_GP* mask;
+    uint64_t PP_GP *cand, *shortl, *sel, *nmask;
+    int32_t PP_GP *counters, *hist, *dirl;
+    float PP_GP *boxes, *nbox;
 };
 #define PP_GROUP 32 // frames per batched launch of the integer stages (kernel-argument table size: 384 B of the 4 KB)
 struct pp_in_group {
