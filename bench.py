@@ -270,7 +270,7 @@ def main():
 
     def make_engine():
         e = eng_mod.Engine(dict(cfg), device_index=local, max_batch=ENG_B, **({} if stub else {"precision": args.precision}))
-        e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
+        e.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias, num_anchor_per_loc=getattr(e, "num_anchor_per_loc", 9)))
         return e
 
     # rank 0 tunes (pp_commit_weights measures the tilings on the device), the others import its table first:
@@ -444,7 +444,7 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
     # -- with an engine of its own (max_batch = 1: the tuner then measures the tilings at ONE frame per launch, where smaller
     # tiles win), as a batch-1 deployment would be built; `..._batch_engine` is the same through the 32-frame engine's tilings
     eng1 = eng_mod.Engine(dict(cfg), device_index=local, max_batch=1, precision=args.precision)
-    eng1.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias))
+    eng1.load_state_dict(synth.seeded_state_dict(0, cls_bias=args.cls_bias, num_anchor_per_loc=eng1.num_anchor_per_loc))
     n = 30
     for tag, e in (("", eng1), ("_batch_engine", eng)):
         det1, cnt1 = e.infer_frame(clouds[0])
@@ -476,7 +476,7 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
     del eng1
     # the same resident pass with a trained-like head bias (few candidates instead of ~900 detections per frame)
     if args.cls_bias is None:
-        eng.load_state_dict(synth.seeded_state_dict(0, cls_bias=-4.6))
+        eng.load_state_dict(synth.seeded_state_dict(0, cls_bias=-4.6, num_anchor_per_loc=eng.num_anchor_per_loc))
         NB = min(len(clouds), eng.max_batch)
         for _ in range(2):
             d, c = eng.infer_batch(clouds[:NB])
@@ -487,7 +487,7 @@ def extras(eng, eng_mod, synth, args, cfg, local, clouds, host, dev, D):
         torch.cuda.synchronize()
         out["value_trained_like_bias"] = round(10 * NB / (time.perf_counter() - t0), 3)
         out["mean_detections_trained_like_bias"] = float(c[:, 0].float().mean())
-        eng.load_state_dict(synth.seeded_state_dict(0))
+        eng.load_state_dict(synth.seeded_state_dict(0, num_anchor_per_loc=eng.num_anchor_per_loc))
     return out
 
 

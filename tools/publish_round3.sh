@@ -18,4 +18,5 @@ cp $O/pmc_g1_fp16s.log $P/r03_pmc_gemm1x1_fp16s.txt
 cp $O/b1_prof.log $P/r03_batch1_kernel_summary.txt
 cp $O/cfg_nuscene.json $P/r03_bench_config_nuscene.json
 cp $O/cfg_ntusl_10cm.json $P/r03_bench_config_ntusl_10cm.json
+cp $O/cfg_nuscene_10class.json $P/r03_bench_config_nuscene_10class.json
 ls -la $P | grep r03

@@ -24,4 +24,5 @@ timeout -k 10 400 bash tools/pmc_g1.sh fp16s r03/y > $O/pmc_g1_fp16s.log 2>&1 ||
 timeout -k 10 200 bash tools/b1_prof.sh r03/b1 > $O/b1_prof.log 2>&1 || true
 timeout -k 10 200 python bench.py --config nuscene --no-cpu-baseline --no-extras > $O/cfg_nuscene.json 2> $O/cfg_nuscene.err
 timeout -k 10 300 python bench.py --config ntusl_10cm --batch 16 --no-cpu-baseline --no-extras > $O/cfg_ntusl_10cm.json 2> $O/cfg_ntusl_10cm.err
-for f in cfg_nuscene cfg_ntusl_10cm; do echo "$f: $(python tools/print_bench.py $O/$f.json | head -1)"; done
+timeout -k 10 200 python bench.py --config nuscene_10class --no-cpu-baseline --no-extras > $O/cfg_nuscene_10class.json 2> $O/cfg_nuscene_10class.err
+for f in cfg_nuscene cfg_nuscene_10class cfg_ntusl_10cm; do echo "$f: $(python tools/print_bench.py $O/$f.json | head -1)"; done
