@@ -2765,6 +2765,7 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         menu.push_back(make_wino4<4, 2, 8>(roofline_layer));       // 16x16 px
         menu.push_back(make_wino4<8, 1, 8>(roofline_layer));       // 16x16 px, 8x2-tile N-tiles
         menu.push_back(make_wino4<8, 2, 8>(roofline_layer));       // 32x8 px
+        if (cin % 16 == 0) wino6_menu(menu, roofline_layer);       // Winograd F(4x4,3x3), 16x16 px (wino6.hip)
         if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
         if (cin == 128) menu.push_back(make_wres<128, 1, 1>()); // 128 KB slab: 128 ch x 16 rows
     }
@@ -2786,12 +2787,13 @@ double model_cost(const Variant& v, int rows, int Hout, int Wout)
     return cost;
 }
 
-bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4 || v.wino == 5) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
+bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4 || v.wino == 5 || v.wino == 6) ? (rows % v.bm == 0) : v.bm <= ((rows + 63) / 64) * 64; }
 // shape limits of a tiling family: wino4_mfma stores float2 rows (even output width); gemm1x1 feeds four N-tiles from one
 // dwordx4 of 4 consecutive pixels of the input plane (pixel count a multiple of 4 -- a 9 x 11 map has 99)
 // conv16 fetches its patches as aligned pixel quads and stores pixel quads (input and output width multiples of 4)
 // (gemm1x1 with a 16-bit tensor has no path for maps that are not a multiple of 4 wide)
-bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 3 && v.io16 && (Wout & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
+// wino6 (opt-in) tiles a map with whole 16 x 16-pixel tiles (stride 1: Hin = Hout)
+bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 6 && ((Wout & 15) || (Hin & 15))) && !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 3 && v.io16 && (Wout & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -2883,6 +2885,14 @@ int pack_layer(pp_ctx* ctx, Layer& L)
         }
     }
     L.rows = rows;
+    if (v.wino == 6) { // F(4x4,3x3): U = G g G^T in the order the four waves fetch their positions (wino6.hip)
+        std::vector<float> pk6;
+        wino6_pack(rowsW.data(), rows, L.cin, pk6);
+        if (L.w) (void)hipFree(L.w);
+        PP_HIP(hipMalloc((void**)&L.w, pk6.size() * sizeof(float)));
+        PP_HIP(hipMemcpy(L.w, pk6.data(), pk6.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
     int taps_eff = taps;
     if (v.wino == 1 || v.wino == 2 || v.wino == 4) { // U = G g G^T per (cout, cin), fp64 on the host; position xi = 4*a + b
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -3094,7 +3104,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         g = (g + 7) & ~7;
         grid = dim3(g, 1, 1);
     }
-    if (v.wino == 4) {
+    if (v.wino == 4 || v.wino == 6) {
         // persistent, ONE 4-wave workgroup per CU (512 registers per lane, 3-deep LDS ring), a multiple of the 8 XCDs.
         // Whole main tiles first; what they leave uncovered goes to strip launches of thin tiles when that needs fewer tiles
         // than rounding the main grid up (same weight image: it depends on the 64-row block and the chunk only).
@@ -3123,7 +3133,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
             hipLaunchKernelGGL(rv.kern, dim3(g), dim3(rv.threads), rv.lds, stream, q);
         };
         const int mw = (Wout / v.pw) * v.pw, mh = (Hout / v.ph) * v.ph;
-        const Variant &sv = wino4_strip_v(), &sh = wino4_strip_h();
+        const Variant &sv = wino4_strip_v(), &sh = wino4_strip_h(); // (wino6 has no strip tilings: shape_ok admits it on maps of whole 16 x 16 tiles only)
         // cost of the slowest workgroup: items are dealt evenly over min(CUs, items) persistent workgroups, a tile takes about
         // 2.4 us per 8-channel chunk + 5 us of epilogue, and a strip launch adds its own rounds plus ~30 us of launch gap and
         // pipeline prologue (at batch 1 the 20 extra launches of a frame cost more than the empty tile area they save: 3.4 ms
@@ -3136,11 +3146,11 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         const int t_main = (mw / v.pw) * (mh / v.ph);
         const int t_right = Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0;
         const int t_bottom = Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0;
-        const double tile_us = 2.4 * (L.cin / 8) + 5.0;
+        const double tile_us = v.wino == 6 ? 1.3 * (L.cin / 8) + 3.0 : 2.4 * (L.cin / 8) + 5.0;
         const double full = rounds(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph)) * tile_us;
         const double split = (rounds(t_main) + rounds(t_right) + rounds(t_bottom)) * tile_us + 30.0 * ((t_right > 0) + (t_bottom > 0));
         const bool no_strips = net->w4_strips == 0, all_strips = net->w4_strips == 2;
-        if ((split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
+        if (v.wino == 4 && (split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
             launch_region(v, 0, 0, mw, mh);
             if (Wout > mw) launch_region(sv, mw, 0, Wout, Hout);
             if (Hout > mh) launch_region(sh, 0, mh, mw, Hout);
@@ -3391,7 +3401,10 @@ int pp_net_create(pp_ctx* ctx)
     }
     for (int l = 0; l < 3; ++l)
         for (int b = 0; b < 4; ++b)
-            PP_HIP(hipMalloc((void**)&net->buf[l][b], (size_t)ctx->max_batch * kC[l] * ((H >> l) + 1) * ((W >> l) + 1) * sizeof(float)));
+        {   // W6_FRONT_PAD floats in front: wino6's dwordx4 patch pieces start one float before a row (row 0 of channel 0 of frame 0 included)
+            PP_HIP(hipMalloc((void**)&net->buf[l][b], ((size_t)ctx->max_batch * kC[l] * ((H >> l) + 1) * ((W >> l) + 1) + W6_FRONT_PAD) * sizeof(float)));
+            net->buf[l][b] += W6_FRONT_PAD;
+        }
     PP_HIP(hipMalloc((void**)&net->up, (size_t)ctx->max_batch * 320 * H * W * sizeof(float)));
     // statistics accumulators: one slot of [NREP][256][2] doubles per normalisation site (<= 24 sites)
     net->stats_bytes = (size_t)ctx->max_batch * 24 * NREP * 320 * 2 * sizeof(double);
@@ -3444,7 +3457,7 @@ void pp_net_destroy(pp_ctx* ctx)
     if (!net) return;
     for (int l = 0; l < 3; ++l)
         for (int b = 0; b < 4; ++b)
-            if (net->buf[l][b]) (void)hipFree(net->buf[l][b]);
+            if (net->buf[l][b]) (void)hipFree(net->buf[l][b] - W6_FRONT_PAD);
     for (Layer& L : net->layers)
         if (L.w) (void)hipFree(L.w);
     void* ptrs[] = {net->up, net->stats, net->aff, net->bn_scale, net->bn_shift, net->head_bias, net->head_bias_perm, net->ones, net->zeros};
@@ -3518,7 +3531,8 @@ int pp_net_commit(pp_ctx* ctx)
         if (can_tune) {
             const size_t nin = std::max((size_t)64 * ctx->gx * ctx->gy, (size_t)320 * H * W);
             const int tb = ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES;
-            PP_HIP(hipMalloc((void**)&tin, ((size_t)tb * nin + 256) * sizeof(float)));
+            PP_HIP(hipMalloc((void**)&tin, ((size_t)tb * nin + 256 + W6_FRONT_PAD) * sizeof(float)));
+            tin += W6_FRONT_PAD;
             PP_HIP(hipMalloc((void**)&tout, ((size_t)tb * 320 * H * W + 256) * sizeof(float)));
             hipLaunchKernelGGL(fill_pattern, dim3(2048), dim3(256), 0, 0, tin, (size_t)tb * nin);
         }
@@ -3529,15 +3543,15 @@ int pp_net_commit(pp_ctx* ctx)
                 const int hin = (L.kind == 0 && L.stride == 2) ? h * 2 : h, win = (L.kind == 0 && L.stride == 2) ? w * 2 : w;
                 if (!can_tune && net->eff_prec == 0) L.var = pick_variant(L.kind, L.stride, L.up, (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout), h, w, ctx->cfg.num_anchor_per_loc == 9);
                 rc = autotune_layer(ctx, L, hin, win, h, w, tin, tout, verbose, can_tune);
-                if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
+                if (rc) { if (tin) { (void)hipFree(tin - W6_FRONT_PAD); (void)hipFree(tout); } return rc; }
             }
             PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(L.var.wino == 3 ? g1_lds(L.var, L.cin) : L.var.lds)));
             if (L.var.kern2) PP_HIP(hipFuncSetAttribute((const void*)L.var.kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
             rc = pack_layer(ctx, L);
-            if (rc) { if (tin) { (void)hipFree(tin); (void)hipFree(tout); } return rc; }
+            if (rc) { if (tin) { (void)hipFree(tin - W6_FRONT_PAD); (void)hipFree(tout); } return rc; }
         }
-        if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin); (void)hipFree(tout); tune_cache_save(); }
+        if (tin) { PP_HIP(hipDeviceSynchronize()); (void)hipFree(tin - W6_FRONT_PAD); (void)hipFree(tout); tune_cache_save(); }
         if (net->up16)
             for (const Layer& L : net->layers)
                 if ((L.kind == 1 && L.var.io16 != 3) || (L.kind == 2 && L.var.io16 != 1) ||
@@ -3813,14 +3827,15 @@ extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
 }
 
 // Executed MFMA flops / algorithmic (direct-convolution) flops of the dominant layer's tiling: Winograd F(2x2,3x3)
-// issues 16 multiplications per 2x2 output tile where the direct form needs 36; split-bf16 issues three MFMAs per product.
+// issues 16 multiplications per 2x2 output tile where the direct form needs 36, F(4x4,3x3) 36 per 4x4 tile against 144;
+// split-bf16 issues three MFMAs per product.
 extern "C" double pp_dominant_executed_ratio(pp_ctx* ctx)
 {
     if (!ctx || !ctx->net) return 1.0;
     pp_net* net = (pp_net*)ctx->net;
     for (const Layer& L : net->layers)
         if (L.kind == 0 && L.level == 0 && L.stride == 1)
-            return (L.var.wino == 1 || L.var.wino == 2 || L.var.wino == 4) ? 4.0 / 9.0 : (L.var.wino == 5 && L.var.prec == 1) ? 3.0 : 1.0; // bf16x3: three MFMAs per product
+            return L.var.wino == 6 ? 0.25 : (L.var.wino == 1 || L.var.wino == 2 || L.var.wino == 4) ? 4.0 / 9.0 : (L.var.wino == 5 && L.var.prec == 1) ? 3.0 : 1.0; // bf16x3: three MFMAs per product
     return 1.0;
 }
 

@@ -108,7 +108,8 @@ struct Variant { // one compiled tiling of conv_mfma
     int bm, bmp, pw, ph, kc, threads, waves, pairs; // pairs = MT*NT tile pairs per wave
     size_t lds;
     char name[48];
-    int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident)
+    int wino = 0; // 1: Winograd F(2x2,3x3) image; 2: slab-resident persistent Winograd; 3: persistent 1x1 GEMM (weights resident); 4: wino4_mfma;
+                  // 5: conv16; 6: Winograd F(4x4,3x3), positions split over the waves (wino6.hip)
     int cin = 0;  // wino == 2: compiled for exactly this Cin
     int prec = 0; // wino == 3 / 5: 0 fp32 MFMA, 1 split-bf16 (bf16x3), 2 plain bf16, 3 fp16 operands
     int io16 = 0; // wino == 3 / 5: bit 0 = the input tensor is fp16, bit 1 = the output tensor (and residual) is (pp_set_precision 4)
@@ -117,5 +118,10 @@ struct Variant { // one compiled tiling of conv_mfma
 
 // conv16.hip: 16-bit operand 3x3 convolutions (fp16 / bf16 / split-bf16) -- menu entries for one layer shape and precision
 void conv16_menu(int stride, int prec, std::vector<Variant>& menu, int io16 = 0);
+
+// wino6.hip: Winograd F(4x4,3x3) on fp32 MFMA (opt-in, PP_WINO6=1) -- menu entry and weight image
+void wino6_menu(std::vector<Variant>& menu, bool roofline_layer);
+void wino6_pack(const float* w /*[rows][cin][3][3]*/, int rows, int cin, std::vector<float>& out);
+constexpr int W6_FRONT_PAD = 64; // floats in front of every tensor a wino6 launch reads: its dwordx4 patch pieces start one float before a row
 
 } // namespace ppc

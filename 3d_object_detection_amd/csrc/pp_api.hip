@@ -60,8 +60,7 @@ extern "C" int pp_stage_profile_end(pp_ctx* ctx, double* ms_h)
     for (size_t i = 0; i + 1 < used; ++i) {
         const int id = ctx->stage_id[i];
         if (id < 0 || id >= PP_ST_COUNT) continue;
-        // an interval is meaningful only between two marks of ONE stream (the per-frame scheme, PP_BATCH_STAGES=0, marks
-        // post-processing on the slots' auxiliary streams: those pairs are skipped, not mis-timed)
+        // an interval is meaningful only between two marks of ONE stream
         if (ctx->stage_stream[i] != ctx->stage_stream[i + 1]) continue;
         PP_HIP(hipEventSynchronize(ctx->stage_ev[i]));
         PP_HIP(hipEventSynchronize(ctx->stage_ev[i + 1]));
@@ -96,14 +95,9 @@ static int create_impl(pp_ctx* ctx)
         PP_HIP(dalloc(&S.pt_rank, mp));
         PP_HIP(dalloc(&S.wave_cnt, mp / 64 + 8));
         PP_HIP(dalloc(&S.occ, (size_t)ctx->gx * ctx->gy));
-        if (b > 0) PP_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-        PP_HIP(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
-        PP_HIP(hipEventCreateWithFlags(&S.ev_post, hipEventDisableTiming));
     }
     PP_HIP(hipMalloc((void**)&ctx->d_pre, sizeof(pp_pre_frame) * ctx->max_batch));
     PP_HIP(hipMalloc((void**)&ctx->d_post, sizeof(pp_post_frame) * ctx->max_batch));
-    PP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    PP_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
     PP_HIP(dalloc(&ctx->pfn_w, 9 * 64));
     PP_HIP(dalloc(&ctx->pfn_scale, 64));
     PP_HIP(dalloc(&ctx->pfn_shift, 64));
@@ -205,14 +199,9 @@ extern "C" void pp_destroy(pp_ctx* ctx)
         void* sp[] = {S.cell_first, S.pt_cell, S.pt_rank, S.wave_cnt, S.occ};
         for (void* q : sp)
             if (q) (void)hipFree(q);
-        if (S.stream) (void)hipStreamDestroy(S.stream);
-        if (S.ev_pre) (void)hipEventDestroy(S.ev_pre);
-        if (S.ev_post) (void)hipEventDestroy(S.ev_post);
     }
     if (ctx->d_pre) (void)hipFree(ctx->d_pre);
     if (ctx->d_post) (void)hipFree(ctx->d_post);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     void* ptrs[] = {ctx->anchors, ctx->rect_x, ctx->rect_y, ctx->rects, ctx->pfn_w, ctx->pfn_scale, ctx->pfn_shift,
                     ctx->f_voxels, ctx->f_coors, ctx->f_npts, ctx->f_num, ctx->f_feat, ctx->f_canvas, ctx->f_mask, ctx->f_pmap,
                     ctx->f_cls, ctx->f_box, ctx->f_dir};

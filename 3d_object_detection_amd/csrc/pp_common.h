@@ -72,8 +72,6 @@ struct pp_slot {
     int32_t* vox_scalars = nullptr; // [4]: istar, P_all
     int32_t* occ = nullptr;         // [gx*gy] occupancy -> summed-area table
     void* post = nullptr;           // pp_post workspace (postprocess.hip)
-    hipStream_t stream = nullptr;   // internal stream of this slot (frames > 0 of a batch)
-    hipEvent_t ev_pre = nullptr, ev_post = nullptr;
 };
 
 struct pp_ctx {
@@ -84,10 +82,9 @@ struct pp_ctx {
     int gx = 0, gy = 0, H = 0, W = 0; // BEV grid and level-1 feature map (H = gx/2 along x, W = gy/2 along y)
     int max_batch = 1;                // frames per batched launch (cfg.max_batch)
     int64_t A = 0;                    // anchors
-    // ---- per-frame scratch of the integer stages: one slot per frame of a batch, so the frames'
-    //      voxelise / mask / post-processing can run concurrently on internal streams ----
+    // ---- per-frame scratch of the integer stages: one slot per frame of a batch (the batched stage kernels look a frame's
+    //      buffers up in device tables built from these) ----
     std::vector<pp_slot> slot;     // [max_batch]; the single-stage entry points use slot 0
-    hipEvent_t ev_fork = nullptr, ev_mid = nullptr;
     pp_pre_frame* d_pre = nullptr;   // [max_batch] device tables (built by pp_build_tables for the current anchor count)
     pp_post_frame* d_post = nullptr;
     int64_t tab_A = -1;

@@ -31,36 +31,65 @@ def frames_per_rank_max(world_size, n_frames):
     return (n_frames + world_size - 1) // world_size
 
 
-def gather_detections(det, cnt, group=None, pad_to=None):
-    """det f32[F, rows, 9], cnt i32[F, 1+C] for this rank's F frames -> lists over ranks, each trimmed to that rank's own F.
-    One collective of fixed-size records (latency-bound: ~32 KB per frame).  Ranks may hold DIFFERENT frame counts (a global
-    batch not divisible by the world size, or a rank with no frame at all): every rank pads its records with zero frames to
-    `pad_to` (default: the maximum over ranks, found with one extra 8-byte all_gather) and appends its true F to the record
-    block, so the receiver can trim."""
+class DetectionGatherer:
+    """The per-step exchange of a timed loop: buffers allocated ONCE, `gather()` only enqueues (pack into the preallocated
+    block, one all_gather) -- no `.item()`, no host-side trimming, nothing that would drain the stream before the next step's
+    launches are enqueued.  Every rank pads its records with zero frames to `pad_to` (the busiest rank's count); how many
+    frames each rank really holds is host knowledge (`frames_for_rank`), so `unpack()` trims AFTER the timed region from
+    `counts`.  `force_collective` runs the collective even for a single rank (the RCCL smoke test on a one-GPU box)."""
+
+    def __init__(self, rows, ncnt, pad_to, device, group=None, force_collective=False):
+        self.group, self.rows, self.ncnt, self.pad_to = group, rows, ncnt, pad_to
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized() and (self.world > 1 or force_collective)
+        width = rows * 9 + ncnt
+        self.block = torch.zeros((max(pad_to, 1), width), dtype=torch.float32, device=device)
+        self.out = torch.zeros((self.world, max(pad_to, 1), width), dtype=torch.float32, device=device)
+        self._views = list(self.out.unbind(0))  # views of one buffer (gloo rejects the _into_tensor form's shape)
+
+    def gather(self, det, cnt):
+        """det f32[F, rows, 9], cnt i32[F, ncnt] (F <= pad_to) -> f32[world, pad_to, rows*9 + ncnt], stream-ordered."""
+        f = det.shape[0]
+        if f > self.pad_to:
+            raise ValueError(f"DetectionGatherer: {f} frames on this rank exceed pad_to = {self.pad_to}")
+        if f:
+            self.block[:f, :self.rows * 9].copy_(det.reshape(f, self.rows * 9))
+            self.block[:f, self.rows * 9:].copy_(cnt.contiguous().view(torch.float32).reshape(f, self.ncnt))
+        if self.collective:
+            dist.all_gather(self._views, self.block, group=self.group)
+        else:
+            self.out[0].copy_(self.block)
+        return self.out
+
+    def unpack(self, counts, out=None):
+        """Host side, after the loop: per-rank (det[F_r, rows, 9], cnt[F_r, ncnt]) lists trimmed to counts[r] frames."""
+        out = self.out if out is None else out
+        dets, cnts = [], []
+        for r in range(self.world):
+            d, c = unpack_records(out[r, :counts[r]], self.rows, self.ncnt)
+            dets.append(d)
+            cnts.append(c)
+        return dets, cnts
+
+
+def gather_detections(det, cnt, group=None, pad_to=None, counts=None, force_collective=False):
+    """One-shot convenience form (NOT for a timed loop: it allocates, and without `counts` it synchronises the host).
+    det f32[F, rows, 9], cnt i32[F, 1+C] for this rank's F frames -> lists over ranks, each trimmed to that rank's own F.
+    Ranks may hold DIFFERENT frame counts (a global batch not divisible by the world size, or a rank with no frame at all): every
+    rank pads its records with zero frames to `pad_to` (default: the maximum over ranks).  `counts` = the frames of every rank when
+    the caller knows them (frames_for_rank); otherwise they are exchanged with one extra 8-byte all_gather and read on the host."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return [det], [cnt]
-    f, rows, ncnt = det.shape[0], det.shape[1], cnt.shape[1]
-    if pad_to is None:
+    f = det.shape[0]
+    if counts is None:
         fs = [torch.zeros(1, dtype=torch.int64, device=det.device) for _ in range(world)]
         dist.all_gather(fs, torch.tensor([f], dtype=torch.int64, device=det.device), group=group)
-        pad_to = max(int(x.item()) for x in fs)
-    if f > pad_to:
-        raise ValueError(f"gather_detections: {f} frames on this rank exceed pad_to = {pad_to}")
-    width = rows * 9 + ncnt
-    block = torch.zeros((pad_to + 1, width), dtype=torch.float32, device=det.device)
-    if f:
-        block[:f] = pack_records(det, cnt)
-    block[pad_to, 0] = float(f)  # exact for any frame count that fits a pass
-    out = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
-    dist.all_gather(list(out.unbind(0)), block, group=group)  # one collective; views of one buffer (gloo rejects the _into_tensor form's shape)
-    dets, cnts = [], []
-    for r in range(world):
-        fr = int(out[r, pad_to, 0].item())
-        d, c = unpack_records(out[r, :fr], rows, ncnt)
-        dets.append(d)
-        cnts.append(c)
-    return dets, cnts
+        counts = [int(x.item()) for x in fs]
+    if pad_to is None:
+        pad_to = max(counts)
+    g = DetectionGatherer(det.shape[1], cnt.shape[1], pad_to, det.device, group=group, force_collective=force_collective)
+    return g.unpack(counts, g.gather(det, cnt))
 
 
 def share_tuning(lib, group=None, src=0):

@@ -302,12 +302,15 @@ def main():
             o += len(p)
         det_h[j].copy_(det[j], non_blocking=True)
         cnt_h[j].copy_(cnt[j], non_blocking=True)
-        if dist:
+        if gatherer:
             # the one collective of the path, once per STEP and stream-ordered behind the step's kernels: this rank's NB
-            # records, zero-padded to the busiest rank's count (a rank without frames still takes part)
-            gathered[0] = shard.gather_detections(det[j, :NB], cnt[j, :NB], pad_to=NB_MAX)
+            # records, zero-padded to the busiest rank's count (a rank without frames still takes part).  Enqueue only -- the
+            # buffers are preallocated and the per-rank trimming happens on the host after the timed region (no .item() here:
+            # a host sync per step would serialise the CPU launch time of the next step behind this step's kernels)
+            gathered[0] = gatherer.gather(det[j, :NB], cnt[j, :NB])
 
     gathered = [None]
+    gatherer = shard.DetectionGatherer(rows, ncnt, NB_MAX, dev) if dist else None
 
     def step_resident(i, j):
         with D.use_stream(compute):
@@ -356,6 +359,14 @@ def main():
     elapsed, prof = timed_region(step_resident, True)
     mean_det = float(cnt_h[:, :, 0].float().mean())
     elapsed_h, _ = timed_region(step_host, False)
+    if gatherer:
+        # after the timed regions: the last step's gathered records, trimmed per rank from host-known frame counts, must hold this
+        # rank's own detections at its slot (the collective really moved them)
+        n_all = args.global_batch if args.global_batch > 0 else world * NB
+        counts = [len(shard.frames_for_rank(r, world, n_all)) for r in range(world)] if args.global_batch > 0 else [NB] * world
+        g_det, g_cnt = gatherer.unpack(counts, gathered[0])
+        assert sum(x.shape[0] for x in g_det) == n_all
+        assert torch.equal(g_cnt[rank].cpu(), cnt[(K - 1) % K, :NB].cpu()) if NB else True
 
     if rank == 0:
         k_ms, k_n, k_flops = prof

@@ -141,13 +141,20 @@ def test_batched_sparse_path_vs_reference(tag, synth, eight_ref):
     assert int(cnt_b[2, 0]) == 0
 
 
-@pytest.mark.parametrize("nb", [32, 8])
-def test_bench_plan_vs_oracle(nb, synth, eight_ref):
+@pytest.mark.parametrize("nb,force", [(32, None), (8, None), (32, "wino4 tw4 bx2"), (32, "wino4 tw8 bx1"), (5, "wino6")])
+def test_bench_plan_vs_oracle(nb, force, synth, eight_ref, monkeypatch):
     """The launch plan bench.py times, pinned to the oracle: Engine(max_batch = frames per pass) exactly as bench.py builds it
     (max_batch 32: the default bench pass, tuned at 16 frames per launch; 8: the per-GPU shape of BASELINE config 5, 64 frames
     over 8 GPUs), nb distinct clouds with the golden cloud (seed 1000) at positions 0 and nb - 1, both against the oracle's
     logits / detections and the reference's own sampled values.  The tilings that ran are printed (compare `extras.tilings`
-    of the bench line).  Reference loop: train.py:219-242."""
+    of the bench line).  At 32 frames the tuner's two near-equal picks for the 400 x 400 layers (`wino4 tw4 bx2` / `wino4 tw8 bx1`:
+    each wins in about half of the runs) are ALSO forced one by one, so whichever plan a bench run lands on has been compared with
+    the oracle at full size; `wino6` (opt-in F(4x4,3x3), 400 x 400 layers only: 200 and 100 are no multiples of 16) rides the same
+    check on a 5-frame pass.  Reference loop: train.py:219-242."""
+    if force:
+        monkeypatch.setenv("PP_FORCE_VARIANT", force)
+        if force == "wino6":
+            monkeypatch.setenv("PP_WINO6", "1")
     pts, refs = eight_ref
     sd, r = refs["rand"]  # bench.py: seeded_state_dict(0), no cls bias
     g = golden("e2e_eight_20cm_rand")
@@ -155,7 +162,9 @@ def test_bench_plan_vs_oracle(nb, synth, eight_ref):
     eng = eng_mod.Engine(make_cfg(synth, "eight_20cm"), max_batch=nb)
     eng.load_state_dict(sd)
     plan = [t["tiling"] for t in eng.layer_tilings()]
-    line = f"[bench plan] max_batch {nb}: " + " | ".join(plan)
+    if force:
+        assert all(force in plan[i] for i in (1, 2, 3)), plan  # the three stride-1 3x3 convolutions at 400 x 400
+    line = f"[bench plan] max_batch {nb}{' forced ' + force if force else ''}: " + " | ".join(plan)
     print(line)
     report(line)
     gold = torch.from_numpy(pts).cuda()
@@ -166,7 +175,7 @@ def test_bench_plan_vs_oracle(nb, synth, eight_ref):
     for f in (0, nb - 1):
         gl = gpu_logits(eng, f)
         check_golden_samples(g, eng.fetch(f, "rpn").cpu().numpy(), gl["cls"], gl["box"], gl["dir"], eng.fetch(f, "feat").cpu().numpy(), 1e-4)
-        compare_frame(r, gl, det_b[f, :cnt_b[f, 0]], cnt_b[f], "aabb", f"bench plan max_batch {nb}, frame {f}")
+        compare_frame(r, gl, det_b[f, :cnt_b[f, 0]], cnt_b[f], "aabb", f"bench plan max_batch {nb}{' forced ' + force if force else ''}, frame {f}")
     # the two copies of the golden cloud ride at opposite ends of the pass (different stage groups at 32): same result
     assert np.array_equal(cnt_b[0], cnt_b[nb - 1])
     np.testing.assert_allclose(det_b[0, :cnt_b[0, 0], :8], det_b[nb - 1, :cnt_b[0, 0], :8], rtol=0, atol=1e-5 * 300)

@@ -41,6 +41,13 @@ def _worker(rank, world, port, n_frames, out):
     dets2, cnts2 = shard.gather_detections(det, cnt)
     same = all(torch.equal(a, b) for a, b in zip(dets, dets2)) and all(torch.equal(a, b) for a, b in zip(cnts, cnts2))
     same &= [d.shape[0] for d in dets] == [len(shard.frames_for_rank(r, world, n_frames)) for r in range(world)]
+    # the timed loop's form: buffers allocated once, gather() only enqueues, trimming from host-known counts afterwards;
+    # two steps through the same buffers (the second with other values must replace the first's)
+    counts = [len(shard.frames_for_rank(r, world, n_frames)) for r in range(world)]
+    g = shard.DetectionGatherer(rows, 4, shard.frames_per_rank_max(world, n_frames), det.device)
+    g.gather(det * 0.5, cnt)
+    d3, c3 = g.unpack(counts, g.gather(det, cnt))
+    same &= all(torch.equal(a, b) for a, b in zip(dets, d3)) and all(torch.equal(a, b) for a, b in zip(cnts, c3))
     merged = shard.merge_in_frame_order(dets, cnts, n_frames)
     ok = abs(float(t0) - 0.1 * world) < 1e-12 and same
     for f, (d, c) in enumerate(merged):
@@ -75,3 +82,19 @@ def test_single_process_gather_is_identity():
     det, cnt = torch.ones((2, 3, 9)), torch.tensor([[3, 1, 1, 1], [2, 1, 1, 0]], dtype=torch.int32)
     d, c = shard.gather_detections(det, cnt)
     assert len(d) == 1 and d[0] is det and c[0] is cnt
+
+
+def test_force_collective_single_rank_gloo():
+    """world_size 1 with force_collective: the pack -> all_gather -> unpack code really runs (the -m gpu twin of this test does
+    the same over RCCL on device tensors, tests/test_gpu_parity.py::test_rccl_single_rank_gather)."""
+    shard = load_pkg("shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        det = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 9)
+        cnt = torch.tensor([[3, 1, 1, 1], [2, 1, 1, 0]], dtype=torch.int32)
+        d, c = shard.gather_detections(det, cnt, pad_to=4, counts=[2], force_collective=True)
+        assert len(d) == 1 and d[0] is not det and torch.equal(d[0], det) and torch.equal(c[0], cnt)
+    finally:
+        dist.destroy_process_group()
