@@ -44,6 +44,7 @@ PROTOTYPES = {
     "pp_load_weights": (ctypes.c_int, [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), ctypes.c_int]),
     "pp_commit_weights": (ctypes.c_int, [c_p]),
     "pp_set_precision": (ctypes.c_int, [c_p, ctypes.c_int]),
+    "pp_effective_precision": (ctypes.c_int, [c_p]),
     "pp_set_anchors": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
     "pp_voxelize": (ctypes.c_int, [c_p, c_p, ctypes.c_int, ctypes.c_int, c_p, c_p, c_p, c_p, c_p]),
     "pp_anchor_mask": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p]),

@@ -3817,6 +3817,13 @@ extern "C" int pp_profile_end(pp_ctx* ctx, double* avg_ms, int32_t* launches, do
     return 0;
 }
 
+extern "C" int pp_effective_precision(pp_ctx* ctx)
+{
+    if (!ctx || !ctx->net || !ctx->weights_ready) return -1;
+    const pp_net* net = (const pp_net*)ctx->net;
+    return net->up16 ? 4 : net->eff_prec;
+}
+
 extern "C" const char* pp_dominant_kernel(pp_ctx* ctx)
 {
     if (!ctx || !ctx->net) return "";

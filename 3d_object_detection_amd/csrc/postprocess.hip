@@ -526,7 +526,7 @@ __device__ __forceinline__ int nms_greedy_wave(const uint64_t* __restrict__ mask
 // ---------------------------------------------------------------- Q6
 __device__ __forceinline__ void nms_reduce_body(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
                                                   const float* __restrict__ boxes, const int32_t* __restrict__ dirl,
-                                                  int32_t* __restrict__ counters, int K, int cb, int32_t* __restrict__ keep_ws,
+                                                  int32_t* __restrict__ counters, int K, int cb,
                                                   float* __restrict__ det, int32_t* __restrict__ det_count)
 {
     __shared__ int s_cnt[PP_MAX_CLASSES];
@@ -540,7 +540,6 @@ __device__ __forceinline__ void nms_reduce_body(pp_config cfg, const uint64_t* _
         // stores into the vmcnt queue, so every tile's fold waited for vmcnt(0) -- the NEXT tile's words included (one memory round
         // trip per tile on the one wave that does the work)
         int* keep = s_out[c];
-        (void)keep_ws;
         const int nk = nms_greedy_wave(mask + (size_t)c * K * cb, n, K, cb, cfg.nms_post_max, keep); // <= 1024 (pp_create)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -625,9 +624,9 @@ __global__ void __launch_bounds__(64) nms_mask(const float* __restrict__ nbox, i
 }
 __global__ void __launch_bounds__(64 * PP_MAX_CLASSES) nms_reduce(pp_config cfg, const uint64_t* __restrict__ mask, const uint64_t* __restrict__ sel,
                                                   const float* __restrict__ boxes, const int32_t* __restrict__ dirl, int32_t* __restrict__ counters,
-                                                  int K, int cb, int32_t* __restrict__ keep_ws, float* __restrict__ det, int32_t* __restrict__ det_count)
+                                                  int K, int cb, float* __restrict__ det, int32_t* __restrict__ det_count)
 {
-    nms_reduce_body(cfg, mask, sel, boxes, dirl, counters, K, cb, keep_ws, det, det_count);
+    nms_reduce_body(cfg, mask, sel, boxes, dirl, counters, K, cb, det, det_count);
 }
 
 __global__ void __launch_bounds__(256) post_init_b(const pp_post_frame* __restrict__ tab, int nwords)
@@ -667,7 +666,7 @@ __global__ void __launch_bounds__(64 * PP_MAX_CLASSES) nms_reduce_b(const pp_pos
                                                     size_t det_fs, int32_t* __restrict__ det_count, int cnt_fs)
 {
     const pp_post_frame F = tab[blockIdx.z];
-    nms_reduce_body(cfg, F.nmask, F.sel, F.boxes, F.dirl, F.counters, K, cb, F.dirl + (size_t)cfg.num_classes * K, det + blockIdx.z * det_fs,
+    nms_reduce_body(cfg, F.nmask, F.sel, F.boxes, F.dirl, F.counters, K, cb, det + blockIdx.z * det_fs,
                     det_count + blockIdx.z * cnt_fs);
 }
 
@@ -709,7 +708,7 @@ static int post_create_one(pp_ctx* ctx, pp_slot& S)
     PP_HIP(hipMalloc((void**)&P->sel, (size_t)n * P->K * sizeof(uint64_t)));
     PP_HIP(hipMalloc((void**)&P->boxes, (size_t)n * P->K * 7 * sizeof(float)));
     PP_HIP(hipMalloc((void**)&P->nbox, (size_t)n * P->K * 6 * sizeof(float)));
-    PP_HIP(hipMalloc((void**)&P->dirl, (size_t)n * P->K * sizeof(int32_t) * 2)); // + keep workspace
+    PP_HIP(hipMalloc((void**)&P->dirl, (size_t)n * P->K * sizeof(int32_t)));
     PP_HIP(hipMalloc((void**)&P->nmask, (size_t)n * P->K * P->cb * sizeof(uint64_t)));
     float thr = c.score_threshold;
     if (!(thr > 0.f && thr < 1.f)) return pp_fail(ctx, PP_E_ARG, "score_threshold must be in (0,1)");
@@ -800,7 +799,7 @@ int pp_postprocess_slot(pp_ctx* ctx, int si, const float* cls, const float* box,
     hipLaunchKernelGGL(nms_mask, dim3(P->cb, P->cb, n), dim3(64), 0, stream, P->nbox, 6, P->counters + 3, 8, P->K, P->cb,
                        c.nms_iou_threshold, nms_mode, P->nmask);
     hipLaunchKernelGGL(nms_reduce, dim3(1), dim3(64 * PP_MAX_CLASSES), 0, stream, c, P->nmask, P->sel, P->boxes, P->dirl, P->counters, P->K, P->cb,
-                       P->dirl + (size_t)n * P->K, det, det_count);
+                       det, det_count);
     PP_HIP(hipGetLastError());
     return pp_stage_mark(ctx, stream, -1);
 }

@@ -211,8 +211,10 @@ class Engine:
     # ------------------------------------------------------------------ weights
     def set_precision(self, mode):
         """MFMA operand type of the convolutions, upsamplers and head: "fp32" (exact, default), "bf16x3" (split-bf16, fp32-equivalent),
-        "fp16" / "bf16" (reduced-precision deploy modes), "fp16s" (fp16 operands and fp16 STORAGE of the 320-channel concat
-        buffer between the upsamplers and the head).  Re-commits the loaded weights for the new tilings."""
+        "fp16" / "bf16" (reduced-precision deploy modes), "fp16s" (fp16 operands and fp16 STORAGE of every activation
+        tensor behind the first convolution: level buffers, residuals, the 320-channel concat buffer; statistics from the unrounded fp32
+        values; needs maps that are multiples of 4 wide at all levels and the 9-anchor head, otherwise it runs as "fp16" --
+        `effective_precision()` says which).  Re-commits the loaded weights for the new tilings."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _lib.check(self.lib.pp_set_precision(self.ctx, self.PRECISIONS[mode]), self.ctx, "pp_set_precision")
@@ -221,6 +223,12 @@ class Engine:
         if changed and self.weights_loaded:
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.pp_commit_weights(self.ctx), self.ctx, "pp_commit_weights")
+
+    def effective_precision(self):
+        """The mode the committed launch plan runs (pp_effective_precision): the requested one, except "fp16s" -> "fp16" where the fp16
+        tensors are not possible; None before the weights are committed."""
+        v = self.lib.pp_effective_precision(self.ctx)
+        return None if v < 0 else {n: k for k, n in self.PRECISIONS.items()}[v]
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
@@ -309,10 +317,12 @@ class Engine:
         det = torch.zeros((self.cfg.num_classes * self.cfg.nms_post_max, 9), dtype=torch.float32, device=self.device)
         cnt = torch.zeros((1 + _lib.PP_MAX_CLASSES,), dtype=torch.int32, device=self.device)
         m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-        _chk(cls.reshape(-1), torch.float32, (self.A,), "postprocess: cls_preds")
-        _chk(box.reshape(-1), torch.float32, (self.A * 7,), "postprocess: box_preds")
-        _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "postprocess: dir_preds")
-        _chk(m.reshape(-1), torch.uint8, (self.A,), "postprocess: anchors_mask")
+        # the kernels get the pointers of the tensors that were CHECKED: reshape(-1) of a strided view is a contiguous copy, and the
+        # pointer of the original would pass the check while the kernel read the strided memory
+        cls = _chk(cls.reshape(-1), torch.float32, (self.A,), "postprocess: cls_preds")
+        box = _chk(box.reshape(-1), torch.float32, (self.A * 7,), "postprocess: box_preds")
+        dr = _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "postprocess: dir_preds")
+        m = _chk(m.reshape(-1), torch.uint8, (self.A,), "postprocess: anchors_mask")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_postprocess(self.ctx, _ptr(cls), _ptr(box), _ptr(dr), _ptr(m), _ptr(det), _ptr(cnt),
                                                int(nms_mode), _stream()), self.ctx, "pp_postprocess")
@@ -326,10 +336,10 @@ class Engine:
         score = self._t((n, k), torch.float32)
         count = self._t((n,), torch.int32)
         m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-        _chk(cls.reshape(-1), torch.float32, (self.A,), "select_candidates: cls_preds")
-        _chk(box.reshape(-1), torch.float32, (self.A * 7,), "select_candidates: box_preds")
-        _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "select_candidates: dir_preds")
-        _chk(m.reshape(-1), torch.uint8, (self.A,), "select_candidates: anchors_mask")
+        cls = _chk(cls.reshape(-1), torch.float32, (self.A,), "select_candidates: cls_preds")  # checked tensors are the ones passed on
+        box = _chk(box.reshape(-1), torch.float32, (self.A * 7,), "select_candidates: box_preds")
+        dr = _chk(dr.reshape(-1), torch.float32, (self.A * 2,), "select_candidates: dir_preds")
+        m = _chk(m.reshape(-1), torch.uint8, (self.A,), "select_candidates: anchors_mask")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pp_select_candidates(self.ctx, _ptr(cls), _ptr(box), _ptr(dr), _ptr(m), _ptr(idx), _ptr(score), _ptr(count),
                                                      _stream()), self.ctx, "pp_select_candidates")

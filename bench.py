@@ -129,6 +129,8 @@ def executed_factor(L):
     tiling issues three bf16 MFMAs per product."""
     if L["wino"] in (1, 2, 4):
         return 4.0 / 9.0
+    if L["wino"] == 6:  # Winograd F(4x4,3x3): 36 multiplies per 4x4 tile against 144
+        return 0.25
     if " p1" in L["tiling"]:
         return 3.0
     return 1.0
@@ -167,17 +169,19 @@ def stage_rooflines(eng, clouds, NB, cfg, passes=3, mfma_peak=F32_MFMA_PEAK_TFLO
     T = int(cfg["max_num_points"])
     gx, gy = int(eng.grid_size[0]), int(eng.grid_size[1])
     HW = eng.H * eng.W
+    act_bytes = 2 if eng.effective_precision() == "fp16s" else 4  # the tensors norm_relu_stats reads and writes are fp16 under fp16s
     bytes_ = {
         "voxelize": 16 * N + P * (16 * T + 16),                       # points read + pillars (voxels, coors, count) written
         "anchor_mask": 3 * 4 * gx * gy + eng.A,                        # occupancy table written + two scan passes, mask written
         "pfn_pmap": P * 16 * T + 256 * P + 4 * gx * gy,                # pillars read, PFN rows + pillar map written
-        "norm_relu_stats": 2 * 4 * HW * (64 + 128 / 4 + 256 / 16),     # block-head maps read + written once, 3 levels
+        "norm_relu_stats": 2 * act_bytes * HW * (64 + 128 / 4 + 256 / 16),  # block-head maps read + written once, 3 levels (stored element size)
         "postprocess": 4 * eng.A + eng.A + 3 * 1000 * (28 + 8 + 28),   # cls logits + mask read, box/dir/anchor rows of <= 1000 candidates per class
     }
     out = {}
     for k, b in bytes_.items():
         t = per_frame[k] * 1e-3
         gbs = b / t / 1e9 if t > 0 else 0.0
+        assert gbs <= HBM_PEAK_GBS, (k, gbs, "a stage cannot move its algorithmic bytes faster than the HBM peak: the byte count is wrong")
         out[k] = {"bound": "hbm", "ms_per_frame": round(per_frame[k], 5), "algorithmic_bytes_per_frame": int(b), "achieved": round(gbs, 2),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}
     til = eng.layer_tilings()
@@ -196,6 +200,7 @@ def stage_rooflines(eng, clouds, NB, cfg, passes=3, mfma_peak=F32_MFMA_PEAK_TFLO
     whole = {"gpu_ms_per_frame": round(total, 5), "algorithmic_gflop": round(alg / 1e9, 2), "executed_gflop": round(ex / 1e9, 2),
              "executed_tflops": round(ex / (total * 1e-3) / 1e12, 2) if total > 0 else 0.0,
              "executed_frac": round(ex / (total * 1e-3) / 1e12 / mfma_peak, 4) if total > 0 else 0.0,
+             "algorithmic_tflops": round(alg / (total * 1e-3) / 1e12, 2) if total > 0 else 0.0,
              "mean_points": N, "mean_pillars": P}
     return out, whole, til
 
@@ -405,7 +410,7 @@ def main():
                                "algorithmic_flops_per_launch": k_flops, "executed_flops_per_launch": k_flops * ratio,
                                "algorithmic_tflops": round(ach, 3),
                                "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
-                                       "count in `algorithmic_*`)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+                                       "count in `algorithmic_*`; F(4x4,3x3): 1/4)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
         else:
             # 16-bit operands: the same layer is no longer bound by the matrix pipe.  Both floors are stated, the binding one
             # (the larger time) is the roofline: HBM with SURVEY 8(d)'s algorithmic bytes (input read once + output written
@@ -425,6 +430,7 @@ def main():
                                "algorithmic_bytes_per_launch": alg_bytes, "executed_flops_per_launch": k_flops * ratio,
                                "floors_ms": {"hbm_8TBps": round(t_hbm, 5), "mfma_16bit_2500TF": round(t_mfma, 5)},
                                "mfma_frac": round(ach * ratio / LP_MFMA_PEAK_TFLOPS, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "algorithmic_tflops": round(ach, 2),  # useful (direct-convolution) flops: bf16x3 EXECUTES three MFMAs per product
                                "note": "16-bit operand mode: floors of this layer per launch in `floors_ms`; the larger one is the bound"}
         if args.precision != "fp32":
             out["tagged"] = (f"reduced-precision deploy mode '{args.precision}': convolutions, upsamplers and head on 16-bit MFMA operands, fp32 accumulation, "

@@ -37,7 +37,9 @@ typedef struct pp_config {
     int32_t grid_size[3];     /* gx, gy, gz (gz must be 1 for the BEV path) */
     int32_t max_voxels;
     int32_t max_num_points;   /* T */
-    int32_t num_point_features; /* F (4) */
+    int32_t num_point_features; /* F: must be 4 for the PFN (its 9 input features x, y, z, i, 3 offsets from the pillar mean, 2 from the
+                                 * pillar centre -- pointpillars8_shared.py:30-60 -- and the (64, 9, 1) weight of the state_dict fix it:
+                                 * pp_pfn / pp_infer_* refuse other values); pp_voxelize alone takes any F >= 3 */
     int32_t max_points;       /* capacity of the per-point workspace (N upper bound) */
     int32_t num_anchor_per_loc; /* anchors per BEV location = head geometry: cls na, box 7*na, dir 2*na rows (reference: 9) */
     int32_t num_classes;      /* <= PP_MAX_CLASSES (reference: 3) */
@@ -71,13 +73,20 @@ int pp_commit_weights(pp_ctx* ctx);
  *   1 split-bf16 "bf16x3" (x = hi + lo, three bf16 MFMAs per product, fp32 accumulation: fp32-equivalent for this network,
  *     meets the fp32 parity bar -- DESIGN.md);
  *   2 bf16 operands;   3 fp16 operands (the reference's deploy arithmetic) -- own tolerance table in DESIGN.md;
- *   4 "fp16s": mode 3 plus fp16 STORAGE of the [320,H,W] concat buffer between the upsamplers and the head (the largest tensor of
- *     the network; TensorRT FP16 engines keep fp16 tensors between layers) -- runs as mode 3 where the maps are not multiples of 16.
- * Accumulation is fp32 and every other activation stays fp32 NCHW in HBM (normalise + ReLU in fp32, round while staging).
+ *   4 "fp16s": mode 3 plus fp16 STORAGE of every activation tensor behind the first convolution -- the level buffers (block-head
+ *     outputs, Resnet2 intermediates, residuals) and the [320,H,W] concat buffer between the upsamplers and the head; TensorRT FP16
+ *     engines keep fp16 tensors between layers.  The first conv still reads the fp32 PFN rows / canvas, the logits stay fp32, and the
+ *     InstanceNorm statistics are accumulated from the UNROUNDED fp32 values of a layer while its consumer normalises the fp16-rounded
+ *     tensor (DESIGN.md tolerance table).  Needs maps that are multiples of 4 pixels wide at all three levels (W a multiple of 16,
+ *     H * W of 64) and the 9-anchor head; otherwise the context runs mode 3 -- pp_effective_precision tells which.
+ * Modes 1 - 3: accumulation is fp32 and every activation stays fp32 NCHW in HBM (normalise + ReLU in fp32, round while staging).
  * A layer whose shape none of the 16-bit tilings takes (maps not a multiple of 4 wide, Cin not a multiple of 16 / 32) keeps its
  * fp32 tiling: pp_layer_tilings reports what runs.  Call before pp_commit_weights (a change of mode invalidates the committed
  * weights until the next commit). */
 int pp_set_precision(pp_ctx* ctx, int mode);
+/* The mode the committed launch plan really runs (pp_set_precision's value, except 4 -> 3 where the fp16 tensors are not possible);
+ * valid after pp_commit_weights, -1 before. */
+int pp_effective_precision(pp_ctx* ctx);
 
 /* Anchor table built by the host mirror of AnchorAssigner.__init__ (anchor_assigner.py:221-298):
  * anchors f32[A,7], cell rectangles i32[A,4] from get_anchor_coor (box_np_ops.py:288-305). Synchronous. */

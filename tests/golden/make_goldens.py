@@ -3,6 +3,7 @@
 
     python tests/golden/make_goldens.py            (needs /root/reference; ~2-4 min)
     python tests/golden/make_goldens.py --only eval   (just eval_ap.npz, seconds)
+    python tests/golden/make_goldens.py --only io     (just kitti_io_ref.npz: train.py's label remap and the anno / dt_info layout)
 
 The reference (1005088h/3d_object_detection, pure Python) never travels: only
 the inputs/outputs captured here are committed.  How each piece is run:
@@ -217,6 +218,86 @@ def make_eval_goldens():
          precision_3d_80=ret["precision"], recall_3d_80=ret["recall"], **res)
 
 
+def ref_function_from_source(path, name):
+    """A top-level function of a reference module that cannot be IMPORTED here (train.py pulls tensorrt, pycuda and matplotlib at its
+    top): the function's own AST node is compiled from the file where it lies and executed in this process -- the reference's code runs,
+    nothing of it is copied; only the inputs / outputs below are committed."""
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def make_io_goldens():
+    """SURVEY 8(f).3 pinned to the reference: (1) train.py:164-184 `changeInfo` (drop boxes without points, label remap) run on a seeded
+    info list; (2) the result layout of a frame -- `Inference.infer_gpu` (inference.py:124-138 on top of get_start_result_anno
+    :724-737) on seeded head outputs, one frame with detections and one without -- which is what train.py:258-265 pickles as dt_info."""
+    install_shims()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    import torch
+    synth = importlib.import_module("3d_object_detection_amd.synth")
+    change_info = ref_function_from_source(os.path.join(REF, "train.py"), "changeInfo")
+    rng = np.random.default_rng(21)
+    vocab = np.array(["car", "truck", "bus", "person", "bicycle", "motorbike", "cone", "vehicle", "pedestrian", "tricycle", "barrier"])
+    infos, inp = [], {"n": [], "name": [], "num_points": [], "location": [], "bbox": []}
+    for f in range(40):
+        n = int(rng.integers(0, 13)) if f % 7 else 0
+        a = {"name": vocab[rng.integers(0, len(vocab), n)].astype("<U10"), "num_points": rng.integers(0, 4, n).astype(np.int32),
+             "location": rng.standard_normal((n, 3)).astype(np.float32), "bbox": rng.standard_normal((n, 4)).astype(np.float32)}
+        infos.append({"velodyne_path": f"seq/velodyne/{f:06d}.bin", "annos": a})
+        inp["n"].append(n)
+        for k in ("name", "num_points", "location", "bbox"):
+            inp[k].append(a[k].copy())
+    change_info(infos)
+    out = {"n": [len(i["annos"]["name"]) for i in infos]}
+    for k in ("name", "num_points", "location", "bbox"):
+        out[k] = [i["annos"][k] for i in infos]
+    cat = lambda xs, dt=None: np.concatenate([np.asarray(x) for x in xs]) if dt is None else np.concatenate([np.asarray(x, dtype=dt) for x in xs])
+
+    # ---- the anno layout of a frame
+    from framework.voxel_generator import VoxelGenerator
+    from framework.anchor_assigner import AnchorAssigner
+    from framework import nms as ref_nms
+    from framework import inference as ref_inf
+
+    def nms_gpu_emulated(dets, thr, device_id=0):
+        keep, _ = ref_nms_from_device_fn(ref_nms.iou_device, ref_nms.nms_postprocess, np.asarray(dets, dtype=np.float32), np.float32(thr), 5)
+        return keep
+
+    ref_inf.nms_gpu = nms_gpu_emulated
+    cfg = synth.load_config("eight_20cm")
+    cfg["device"] = torch.device("cpu")
+    cfg["create_mask_gpu"] = 0
+    VoxelGenerator(cfg)
+    aa = AnchorAssigner(cfg)
+    inf = ref_inf.Inference(cfg, aa)
+    A = aa.anchors.shape[0]
+    g = torch.Generator().manual_seed(5)
+    ex = {"anchors_mask": torch.ones((1, A), dtype=torch.bool)}
+    annos = []
+    for bias in (-6.0, -30.0):  # a frame with detections, a frame without
+        preds = {"cls_preds": torch.randn((1, A, 1), generator=g) + bias, "box_preds": torch.randn((1, A, 7), generator=g) * 0.1,
+                 "dir_preds": torch.randn((1, A, 2), generator=g)}
+        annos.append(inf.infer_gpu(ex, preds)[0])
+    names = list(aa.class_masks.keys())
+    a0, a1 = annos
+    assert a0["score"].shape[0] > 10 and len(a1["name"]) == 0
+    layout = lambda a: np.array([f"{k}|{np.asarray(v).dtype.str}|{','.join(map(str, np.asarray(v).shape))}" for k, v in a.items()])
+    save("kitti_io_ref",
+         in_n=np.array(inp["n"], np.int32), in_name=cat(inp["name"], "<U10"), in_num_points=cat(inp["num_points"]), in_location=cat(inp["location"]),
+         in_bbox=cat(inp["bbox"]),
+         out_n=np.array(out["n"], np.int32), out_name=cat(out["name"], "<U10"), out_name_dtype=np.array([np.asarray(x).dtype.str for x in out["name"]]),
+         out_num_points=cat(out["num_points"]), out_location=cat(out["location"]), out_bbox=cat(out["bbox"]),
+         class_names=np.array(names), anno_layout=layout(a0), empty_layout=layout(a1),
+         det_location=a0["location"], det_dimensions=a0["dimensions"], det_rotation_y=a0["rotation_y"], det_score=a0["score"],
+         det_cls=np.array([names.index(s) for s in a0["name"]], np.int32), det_name=np.asarray(a0["name"]))
+    print("io goldens: boxes", int(np.sum(inp["n"])), "->", int(np.sum(out["n"])), "| detections", a0["score"].shape[0])
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)
@@ -416,8 +497,12 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "eval":
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only == "eval":
         make_eval_goldens()
+    elif only == "io":
+        make_io_goldens()
     else:
         main()
         make_eval_goldens()
+        make_io_goldens()

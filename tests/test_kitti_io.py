@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_pkg
+from conftest import golden, load_pkg
 
 
 def _info(path, names, npts):
@@ -72,42 +72,98 @@ def test_records_to_annos_and_detection_pickle(tmp_path):
     assert len(back) == 2 and np.array_equal(back[0]["score"], annos[0]["score"]) and list(back[0]["name"]) == list(annos[0]["name"])
 
 
+def test_remap_and_anno_layout_vs_reference_fixture(tmp_path):
+    """tests/golden/kitti_io_ref.npz = the reference itself run by make_goldens.py --only io: train.py:164-184 `changeInfo` on a
+    seeded 40-frame info list (200 boxes, 142 left), and the anno dicts `Inference.infer_gpu` returns (inference.py:124-138,
+    724-737) for a frame with 764 detections and an empty one -- what train.py:258-265 pickles as dt_info."""
+    io = load_pkg("kitti_io")
+    g = golden("kitti_io_ref")
+    infos, o = [], 0
+    for f, n in enumerate(g["in_n"]):
+        sl = slice(o, o + int(n))
+        infos.append({"velodyne_path": f"seq/velodyne/{f:06d}.bin",
+                      "annos": {"name": g["in_name"][sl].copy(), "num_points": g["in_num_points"][sl].copy(), "location": g["in_location"][sl].copy(),
+                                "bbox": g["in_bbox"][sl].copy()}})
+        o += int(n)
+    persons = io.remap_classes(infos)
+    assert persons == int((g["in_name"][g["in_num_points"] > 0] == "person").sum())
+    o = 0
+    for f, n in enumerate(g["out_n"]):
+        a, sl = infos[f]["annos"], slice(o, o + int(n))
+        assert len(a["name"]) == n, f
+        if n or len(g["in_name"]):  # the reference leaves frames without boxes untouched
+            assert list(a["name"]) == list(g["out_name"][sl]), f
+        assert np.array_equal(a["num_points"], g["out_num_points"][sl]) and np.array_equal(a["location"], g["out_location"][sl])
+        assert np.array_equal(a["bbox"], g["out_bbox"][sl])
+        if g["in_n"][f]:
+            assert a["name"].dtype.str == g["out_name_dtype"][f]
+        o += int(n)
+    # the anno layout: key order, dtypes, shapes and values of a frame with detections and of an empty frame
+    k = g["det_score"].shape[0]
+    det = np.zeros((2, k + 5, 9), np.float32)
+    det[0, :k] = np.concatenate([g["det_location"], g["det_dimensions"], g["det_rotation_y"][:, None], g["det_score"][:, None],
+                                 g["det_cls"][:, None].astype(np.float32)], axis=1)
+    cnt = np.zeros((2, 4), np.int32)
+    cnt[0, 0] = k
+    annos = io.annos_from_records(det, cnt, list(g["class_names"]))
+    layout = lambda a: [f"{key}|{np.asarray(v).dtype.str}|{','.join(map(str, np.asarray(v).shape))}" for key, v in a.items()]
+    assert layout(annos[0]) == list(g["anno_layout"])
+    assert layout(annos[1]) == list(g["empty_layout"])
+    assert list(annos[0]["name"]) == list(g["det_name"])
+    for key in ("location", "dimensions", "rotation_y", "score"):
+        assert np.array_equal(annos[0][key], g["det_" + key])
+    io.save_detections(tmp_path / "r" / "dt_info.pkl", annos)
+    back = io.load_detections(tmp_path / "r" / "dt_info.pkl")
+    assert layout(back[0]) == list(g["anno_layout"]) and layout(back[1]) == list(g["empty_layout"])
+
+
 @pytest.mark.gpu
-def test_run_sequence_matches_dropin_loop(tmp_path, synth):
-    """.bin files -> run_sequence (pp_infer_batch, 2 frames per pass, ragged tail) must give the annos the
-    reference-style per-frame loop gives on the drop-in classes."""
+def test_run_sequence_vs_oracle(tmp_path, synth):
+    """.bin files -> run_sequence (pp_infer_batch, 2 frames per pass, ragged tail) against the CPU ORACLE frame by frame
+    (tests/frame_check.compare_frame: mask bit-exact, every logit bounded, the selection exact on the GPU's own logits, every oracle row
+    matched by anchor id within 1e-3 or explained) -- the body of train.py:218-242 on the product path."""
+    from frame_check import compare_frame, gpu_logits, oracle_frame
+    from oracle import pp_oracle as O
     pkg = load_pkg()
     pkg.install()
     import framework.voxel_generator as vg
-    import framework.anchor_assigner as aa
-    import framework.dataset as ds
-    import framework.inference as inf
     import networks.pointpillars8_shared as shared
     io = load_pkg("kitti_io")
+    eng_mod = load_pkg("engine")
     cfg = synth.load_config("nuscene")
     cfg["device"] = torch.device("cuda:0")
     cfg["max_batch"] = 2
-    voxel_generator = vg.VoxelGenerator(cfg)
-    anchor_assigner = aa.AnchorAssigner(cfg)
-    inference = inf.Inference(cfg, anchor_assigner)
-    infer_data = ds.InferData(cfg, voxel_generator, anchor_assigner, torch.float32)
+    vg.VoxelGenerator(cfg)
     net = shared.PointPillars(cfg)
     net.to(cfg["device"])
-    net.load_state_dict(synth.seeded_state_dict(4, cls_bias=-3.0))
+    sd = synth.seeded_state_dict(4, cls_bias=-3.0)
+    net.load_state_dict(sd)
     net.eval()
-    paths = []
+    paths, clouds = [], []
     for i in range(3):
         p = tmp_path / f"{i:06d}.bin"
-        synth.lidar_cloud("nuscene", seed=40 + i, n_points=9000 + 1000 * i).tofile(p)
+        clouds.append(synth.lidar_cloud("nuscene", seed=40 + i, n_points=9000 + 1000 * i))
+        clouds[-1].tofile(p)
         paths.append(p)
-    names = list(anchor_assigner.class_masks.keys())
-    got = io.run_sequence(cfg, paths, names, batch=2)
-    assert len(got) == 3
-    for p, g in zip(paths, got):
-        example = infer_data.get(io.read_velodyne(p))
-        with torch.no_grad():
-            ref = inference.infer_gpu(example, net(example))[0]
-        assert len(ref["score"]) > 0
-        assert list(g["name"]) == list(ref["name"])
+    names = list(O.make_anchors(O.voxel_setup(synth.load_config("nuscene")))["class_masks"].keys())
+    eng = eng_mod.engine_for(cfg)
+
+    def rows_of(anno):
+        k = len(anno["score"])
+        det = np.concatenate([anno["location"].reshape(k, 3), anno["dimensions"].reshape(k, 3), np.asarray(anno["rotation_y"]).reshape(k, 1),
+                              np.asarray(anno["score"]).reshape(k, 1), np.array([names.index(n) for n in anno["name"]], np.float32).reshape(k, 1)],
+                             axis=1).astype(np.float32)
+        cnt = np.array([k] + [int((det[:, 8] == c).sum()) for c in range(len(names))], np.int32)
+        return det, cnt
+
+    got = io.run_sequence(cfg, paths, names, batch=2)         # passes: frames (0, 1), then the ragged tail (2)
+    assert len(got) == 3 and all(len(g["score"]) > 0 for g in got)
+    det, cnt = rows_of(got[2])                                 # the engine still holds the last pass: frame 2 at index 0
+    compare_frame(oracle_frame(synth, "nuscene", clouds[2], sd), gpu_logits(eng, 0), det, cnt, "aabb", "run_sequence nuscene frame 2 (tail pass)")
+    again = io.run_sequence(cfg, paths[:2], names, batch=2)   # now the engine holds frames 0 and 1
+    for f in range(2):
+        det, cnt = rows_of(again[f])
+        compare_frame(oracle_frame(synth, "nuscene", clouds[f], sd), gpu_logits(eng, f), det, cnt, "aabb", f"run_sequence nuscene frame {f}")
+        assert list(again[f]["name"]) == list(got[f]["name"])
         for key in ("location", "dimensions", "rotation_y", "score"):
-            np.testing.assert_allclose(g[key], ref[key], rtol=0, atol=1e-3)  # dense-canvas loop vs fused sparse path
+            np.testing.assert_allclose(again[f][key], got[f][key], rtol=0, atol=1e-4)
