@@ -320,7 +320,8 @@ with torch.cuda.stream(side):                      # a non-default stream, as be
         out = g.gather(det, cnt)                   # enqueue only
         d, c = g.unpack([f], out)                  # host-known count
         side.synchronize()
-        ok &= torch.equal(d[0], det) and torch.equal(c[0], cnt) and d[0].data_ptr() != det.data_ptr()
+        ok &= torch.equal(d[0], det) and torch.equal(c[0], cnt) and (f == 0 or d[0].data_ptr() != det.data_ptr())
+        if not ok: print('step', step, 'mismatch'); break
 d2, c2 = shard.gather_detections(torch.ones((2, rows, 9), device=dev), torch.full((2, ncnt), 7, dtype=torch.int32, device=dev), force_collective=True)
 torch.cuda.synchronize()
 ok &= d2[0].shape == (2, rows, 9) and bool((d2[0] == 1).all()) and bool((c2[0] == 7).all())
