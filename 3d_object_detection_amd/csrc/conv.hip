@@ -1169,6 +1169,24 @@ __global__ void __launch_bounds__(256, 1) wino4_mfma(const ConvP p)
     int s_tab = 0, r_tab = 0;
     auto load_aff = [&](int f_) {
         float* dst = aff + s_tab * 640;
+        if (p.pre == PRE_STATS) {
+            // one-frame launches (launch_conv, B == 1): the producer's fp64 sums are finalised HERE, once per workgroup, instead of by a
+            // norm_finalize launch in front of every layer (4.7 us + a launch boundary each, 14 per frame at batch 1) -- same fp64
+            // formula, bit-identical (scale, shift)
+            const double* pa = p.pre_acc + (size_t)f_ * p.pre_fs;
+            for (int c = tid; c < p.Cin; c += C::THREADS) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) { s += pa[((size_t)r * p.Cin + c) * 2]; q += pa[((size_t)r * p.Cin + c) * 2 + 1]; }
+                const double mean = s * p.pre_inv_n;
+                double var = q * p.pre_inv_n - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const double rstd = 1.0 / sqrt(var + (double)p.eps);
+                dst[c] = (float)rstd;
+                dst[320 + c] = (float)(-mean * rstd);
+            }
+            return;
+        }
         for (int c = tid; c < p.Cin; c += C::THREADS) {
             dst[c] = p.pre_scale[(size_t)f_ * p.aff_fs + c];
             dst[320 + c] = p.pre_shift[(size_t)f_ * p.aff_fs + c];
@@ -2775,6 +2793,8 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
 // strip of 4 x 64 px tiles and a bottom strip of 64 x 4 px tiles -- 100 x 100: 36 + 2 + 2 tiles instead of 49 mostly-empty ones
 static Variant& wino4_strip_v() { static Variant v = make_wino4<2, 1, 8>(false); return v; }  // 4 px wide, 64 px tall
 static Variant& wino4_strip_h() { static Variant v = make_wino4<16, 2, 8>(false); return v; } // 64 px wide, 4 px tall
+static Variant& wino6_strip_v_() { static Variant v = wino6_strip_v(); return v; }
+static Variant& wino6_strip_h_() { static Variant v = wino6_strip_h(); return v; }
 
 // cost model: wavefronts are dealt to 1024 SIMDs; a SIMD's time ~ (its wave count) x (tile pairs per wave).
 double model_cost(const Variant& v, int rows, int Hout, int Wout)
@@ -2792,8 +2812,8 @@ bool variant_ok(const Variant& v, int rows) { return (v.wino == 2 || v.wino == 4
 // dwordx4 of 4 consecutive pixels of the input plane (pixel count a multiple of 4 -- a 9 x 11 map has 99)
 // conv16 fetches its patches as aligned pixel quads and stores pixel quads (input and output width multiples of 4)
 // (gemm1x1 with a 16-bit tensor has no path for maps that are not a multiple of 4 wide)
-// wino6 (opt-in) tiles a map with whole 16 x 16-pixel tiles (stride 1: Hin = Hout)
-bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 6 && ((Wout & 15) || (Hin & 15))) && !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 3 && v.io16 && (Wout & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
+// wino6 works on whole 4x4 output tiles and dwordx4 rows (maps a multiple of 4 in both directions; stride 1: Hin = Hout)
+bool shape_ok(const Variant& v, int Hin, int Win, int Wout) { return !(v.wino == 6 && ((Wout & 3) || (Hin & 3))) && !(v.wino == 4 && (Wout & 1)) && !(v.wino == 3 && ((Hin * Win) & 3)) && !(v.wino == 3 && v.io16 && (Wout & 3)) && !(v.wino == 5 && ((Win & 3) || (Wout & 3))); }
 // LDS bytes of a persistent 1x1 GEMM for a given K
 size_t g1_lds(const Variant& v, int K) { return ((size_t)K * v.bmp + (size_t)8 * 2 * K) * sizeof(float); }
 
@@ -3041,6 +3061,8 @@ constexpr size_t STAT_FS = (size_t)24 * NREP * 320 * 2; // doubles of statistics
 
 static unsigned long long* g_stamp_buf = nullptr; // diagnostic builds only
 
+static bool getenv_flag_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
+
 int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, float* out, const float* res,
                 const NormRef& pre, double* stat_acc, int stat_C, int Hout, int Wout, hipStream_t stream,
                 float* out_box = nullptr, float* out_dir = nullptr, int B = 1, size_t out_fs = 0, size_t in_fs = 0,
@@ -3077,7 +3099,11 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         p.pmap_fs = (size_t)Hin * Win;
         p.feat_fs = (size_t)ctx->cfg.max_voxels * 64;
     }
-    if (pre.mode == PRE_STATS && net->aff && L.cin <= 320) {
+    // one frame per launch: the kernels that can finalise the producer's statistics in their prologue (conv_mfma, wino_res, gemm1x1, wino4_mfma)
+    // do so, instead of a norm_finalize launch in front of the layer -- 14 launches of 4.7 us + a boundary each per frame at batch 1.
+    // (Batched launches keep norm_finalize: a persistent workgroup would redo the fp64 finalisation at every frame change.)
+    const bool fin_in_kernel = B == 1 && (L.var.wino == 0 || L.var.wino == 2 || L.var.wino == 3 || L.var.wino == 4) && !getenv_flag_off("PP_FIN_IN_KERNEL");
+    if (pre.mode == PRE_STATS && net->aff && L.cin <= 320 && !fin_in_kernel) {
         hipLaunchKernelGGL(norm_finalize, dim3(B), dim3(320), 0, stream, pre.acc, pre.fs, L.cin, pre.inv_n, p.eps, net->aff, (size_t)640);
         p.pre = PRE_AFFINE; p.pre_scale = net->aff; p.pre_shift = net->aff + 320; p.aff_fs = 640;
     }
@@ -3133,7 +3159,7 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
             hipLaunchKernelGGL(rv.kern, dim3(g), dim3(rv.threads), rv.lds, stream, q);
         };
         const int mw = (Wout / v.pw) * v.pw, mh = (Hout / v.ph) * v.ph;
-        const Variant &sv = wino4_strip_v(), &sh = wino4_strip_h(); // (wino6 has no strip tilings: shape_ok admits it on maps of whole 16 x 16 tiles only)
+        const Variant &sv = v.wino == 6 ? wino6_strip_v_() : wino4_strip_v(), &sh = v.wino == 6 ? wino6_strip_h_() : wino4_strip_h();
         // cost of the slowest workgroup: items are dealt evenly over min(CUs, items) persistent workgroups, a tile takes about
         // 2.4 us per 8-channel chunk + 5 us of epilogue, and a strip launch adds its own rounds plus ~30 us of launch gap and
         // pipeline prologue (at batch 1 the 20 extra launches of a frame cost more than the empty tile area they save: 3.4 ms
@@ -3146,11 +3172,11 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         const int t_main = (mw / v.pw) * (mh / v.ph);
         const int t_right = Wout > mw ? pp_div_up(Wout - mw, sv.pw) * pp_div_up(Hout, sv.ph) : 0;
         const int t_bottom = Hout > mh ? pp_div_up(mw, sh.pw) * pp_div_up(Hout - mh, sh.ph) : 0;
-        const double tile_us = v.wino == 6 ? 1.3 * (L.cin / 8) + 3.0 : 2.4 * (L.cin / 8) + 5.0;
+        const double tile_us = v.wino == 6 ? 1.9 * (L.cin / 8) + 3.5 : 2.4 * (L.cin / 8) + 5.0;
         const double full = rounds(pp_div_up(Wout, v.pw) * pp_div_up(Hout, v.ph)) * tile_us;
         const double split = (rounds(t_main) + rounds(t_right) + rounds(t_bottom)) * tile_us + 30.0 * ((t_right > 0) + (t_bottom > 0));
         const bool no_strips = net->w4_strips == 0, all_strips = net->w4_strips == 2;
-        if (v.wino == 4 && (split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
+        if ((split < full || all_strips) && mw > 0 && mh > 0 && !no_strips && (Wout > mw || Hout > mh)) {
             launch_region(v, 0, 0, mw, mh);
             if (Wout > mw) launch_region(sv, mw, 0, Wout, Hout);
             if (Hout > mh) launch_region(sh, 0, mh, mw, Hout);
@@ -3448,6 +3474,8 @@ int pp_net_create(pp_ctx* ctx)
         PP_HIP(hipFuncSetAttribute((const void*)L.var.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.var.lds));
     PP_HIP(hipFuncSetAttribute((const void*)wino4_strip_v().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_strip_v().lds));
     PP_HIP(hipFuncSetAttribute((const void*)wino4_strip_h().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino4_strip_h().lds));
+    PP_HIP(hipFuncSetAttribute((const void*)wino6_strip_v_().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino6_strip_v_().lds));
+    PP_HIP(hipFuncSetAttribute((const void*)wino6_strip_h_().kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino6_strip_h_().lds));
     return 0;
 }
 

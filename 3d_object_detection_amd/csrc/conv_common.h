@@ -119,8 +119,10 @@ struct Variant { // one compiled tiling of conv_mfma
 // conv16.hip: 16-bit operand 3x3 convolutions (fp16 / bf16 / split-bf16) -- menu entries for one layer shape and precision
 void conv16_menu(int stride, int prec, std::vector<Variant>& menu, int io16 = 0);
 
-// wino6.hip: Winograd F(4x4,3x3) on fp32 MFMA (opt-in, PP_WINO6=1) -- menu entry and weight image
+// wino6.hip: Winograd F(4x4,3x3) on fp32 MFMA -- menu entry, the strip tilings of its region launches, the weight image
 void wino6_menu(std::vector<Variant>& menu, bool roofline_layer);
+Variant wino6_strip_v(); // 4 px wide, 64 px tall
+Variant wino6_strip_h(); // 64 px wide, 4 px tall
 void wino6_pack(const float* w /*[rows][cin][3][3]*/, int rows, int cin, std::vector<float>& out);
 constexpr int W6_FRONT_PAD = 64; // floats in front of every tensor a wino6 launch reads: its dwordx4 patch pieces start one float before a row
 

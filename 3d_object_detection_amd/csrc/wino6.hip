@@ -745,13 +745,18 @@ Variant make_wino6(bool roofline_layer)
 
 } // namespace
 
-// Opt-in (PP_WINO6=1): measured on MI355X (profiles/r04_wino6_ablation.txt) the kernel is correct but SLOWER than wino4_mfma on the
-// roofline layer (2.05 against 1.77 ms per 32-frame launch) -- DESIGN.md section 7 has the account.  16 x 16-pixel tiles only.
+// In the tuner's menu by default (PP_WINO6=0 removes it).  Measured on MI355X (profiles/r04_wino6_ablation.txt, r04 bench): slower than wino4_mfma on
+// the 64-channel 400 x 400 layers (952 against 852 us per 16-frame launch), faster on the 128-channel 200 x 200 and 256-channel 100 x 100 layers
+// (710 / 757 us per 16-frame launch, 72 / 70 against 82 / 83 us at one frame per launch), where a tile carries 16 / 32 chunks per epilogue -- the
+// tuner decides per layer.
 void wino6_menu(std::vector<Variant>& menu, bool roofline_layer)
 {
-    const char* e = getenv("PP_WINO6"); // read per call (commit time only): the parity test switches it on for its own engines
-    if (e && e[0] == '1') menu.push_back(make_wino6<4>(roofline_layer)); // 16 x 16 px
+    const char* e = getenv("PP_WINO6"); // read per call (commit time only)
+    if (!(e && e[0] == '0')) menu.push_back(make_wino6<4>(roofline_layer)); // 16 x 16 px
 }
+// strip tilings of the region launches (launch_conv): a map that is no multiple of 16 x 16 is covered by whole main tiles plus thin tiles
+Variant wino6_strip_v() { return make_wino6<1>(false); }  // 4 px wide, 64 px tall
+Variant wino6_strip_h() { return make_wino6<16>(false); } // 64 px wide, 4 px tall
 
 // Transformed weights U = G g G^T (fp64 on the host, rounded once) in the order the waves fetch them:
 //   [cout block][k-step][wave][local position][lane = (cin quad lane kq) * 16 + m][M-tile]  =  U[block*64 + mt*16 + m][4 s + kq][i][jj]

@@ -149,12 +149,10 @@ def test_bench_plan_vs_oracle(nb, force, synth, eight_ref, monkeypatch):
     logits / detections and the reference's own sampled values.  The tilings that ran are printed (compare `extras.tilings`
     of the bench line).  At 32 frames the tuner's two near-equal picks for the 400 x 400 layers (`wino4 tw4 bx2` / `wino4 tw8 bx1`:
     each wins in about half of the runs) are ALSO forced one by one, so whichever plan a bench run lands on has been compared with
-    the oracle at full size; `wino6` (opt-in F(4x4,3x3), 400 x 400 layers only: 200 and 100 are no multiples of 16) rides the same
-    check on a 5-frame pass.  Reference loop: train.py:219-242."""
+    the oracle at full size; `wino6` (F(4x4,3x3): the tuner's pick for the 200 x 200 and 100 x 100 layers) is forced on all 13 stride-1
+    layers of a 5-frame pass, main + strip launches included.  Reference loop: train.py:219-242."""
     if force:
         monkeypatch.setenv("PP_FORCE_VARIANT", force)
-        if force == "wino6":
-            monkeypatch.setenv("PP_WINO6", "1")
     pts, refs = eight_ref
     sd, r = refs["rand"]  # bench.py: seeded_state_dict(0), no cls bias
     g = golden("e2e_eight_20cm_rand")

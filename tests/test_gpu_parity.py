@@ -223,7 +223,7 @@ def test_backbone_small(norm, fw, synth):
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("force", ["g1x1", "wres", "wino tw8", "wino tw4", "wino tw8 w1x4 bx1 kc4", "wino tw8 w2x4", "wino4 tw4 bx2", "wino4 tw8 bx1", "wino4 tw8 bx2",
+@pytest.mark.parametrize("force", ["g1x1", "wres", "wino tw8", "wino tw4", "wino tw8 w1x4 bx1 kc4", "wino tw8 w2x4", "wino4 tw4 bx2", "wino4 tw8 bx1", "wino4 tw8 bx2", "wino6 tw4",
                                    "k3s1 tw16 w1x4 t4x4", "k3s1 tw4 w2x2 t2x2", "k3s1 tw8 w2x2 t4x5"])
 def test_backbone_forced_tiling(force, fw, synth, monkeypatch):
     """Every tiling family (Winograd F(2x2,3x3) and direct, exact and masked-edge shapes) must give the
@@ -273,9 +273,11 @@ def test_backbone_conv16_forced_tiling(force, mode, tol, fw, synth, monkeypatch)
     net.precision("fp32")
 
 
-@pytest.mark.parametrize("force,strips", [("wino4 tw4 bx2", "2"), ("wino4 tw8 bx1", "2"), ("wino4 tw8 bx2", "2"), ("wino4 tw4 bx2", "0")])
+@pytest.mark.parametrize("force,strips", [("wino4 tw4 bx2", "2"), ("wino4 tw8 bx1", "2"), ("wino4 tw8 bx2", "2"), ("wino4 tw4 bx2", "0"),
+                                          ("wino6 tw4", "2"), ("wino6 tw4", "0")])
 def test_backbone_wino4_edge_maps(force, strips, fw, synth, monkeypatch):
-    """wino4_mfma on maps that are no multiple of its tile: 72 x 88 canvas -> 36 x 44 (dwordx4 rows), 18 x 22 (width = 2 mod 4:
+    """wino4_mfma (and wino6_mfma: its 36 x 44 level -- the other two are no multiples of 4 and keep other kernels -- as 2 x 2 main tiles +
+    4 x 64 / 64 x 4 strip tiles, or as 3 x 3 rounded-up tiles with masked lanes) on maps that are no multiple of its tile: 72 x 88 canvas -> 36 x 44 (dwordx4 rows), 18 x 22 (width = 2 mod 4:
     the dwordx2 form of the epilogue) and 9 x 11 (odd: another kernel takes over) maps, with the region launches forced
     (PP_W4_STRIPS=2: whole main tiles + right / bottom strips of thin tiles, regions starting off a multiple of 4) and disabled,
     against the CPU oracle's backbone."""
@@ -351,12 +353,11 @@ def test_rccl_single_rank_gather():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_backbone_wino6_opt_in(fw, synth, monkeypatch):
+def test_backbone_wino6_all_levels(fw, synth, monkeypatch):
     """wino6_mfma -- Winograd F(4x4,3x3), positions split over the waves, all vector-memory operations counted by the kernel itself
-    (csrc/wino6.hip; opt-in, PP_WINO6=1) -- forced on every stride-1 3x3 convolution: 128 x 128 canvas -> maps 64, 32 and 16 (whole
+    (csrc/wino6.hip) -- forced on every stride-1 3x3 convolution: 128 x 128 canvas -> maps 64, 32 and 16 (whole
     16 x 16-pixel tiles at all three levels, 16 / 4 / 1 tiles per frame: more workgroups than items at the coarse levels), against
     the CPU oracle's backbone (networks/pointpillars8_shared.py:114-181)."""
-    monkeypatch.setenv("PP_WINO6", "1")
     monkeypatch.setenv("PP_FORCE_VARIANT", "wino6")
     cfg = small_cfg(synth, 128, 128)
     fw["vg"].VoxelGenerator(cfg)

@@ -46,7 +46,7 @@ int main(int argc, char** argv)
     p.in = dx; p.w = dw; p.out = dy; p.res = dres; p.Cin = C; p.Hin = H; p.Win = W; p.Cout = Cout; p.Hout = H; p.Wout = W;
     p.pre = PRE_AFFINE; p.pre_scale = dsc; p.pre_shift = dsh; p.aff_fs = 0; p.stat_acc = dst; p.stat_C = C; p.stat_fs = stat_fs;
     p.dbg = dbg; p.in_fs = fs; p.out_fs = fs; p.res_fs = fs; p.nb = B;
-    (void)twt; Variant v = make_wino6<4>(false); // the library instantiates 16 x 16-pixel tiles only
+    Variant v = twt == 4 ? make_wino6<4>(false) : twt == 1 ? make_wino6<1>(false) : make_wino6<16>(false);
     p.rx0 = 0; p.ry0 = 0; p.rx1 = W; p.ry1 = H; p.rnbx = (W + v.pw - 1) / v.pw; p.rnby = (H + v.ph - 1) / v.ph;
     const int total = p.rnbx * p.rnby * (Cout / 64) * B;
     int g = 256; if (g > total) g = total; g = (g + 7) & ~7;
