@@ -683,14 +683,22 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
             { unsigned long long e2b_ = 0; W6_STAMP(e2b_) st_epi4 += e2b_ - e2_; }
 #endif
             if (p.stat_acc) {
-                double* dst = p.stat_acc + fz * p.stat_fs + ((size_t)(blockIdx.x % NREP) * p.stat_C + co0 + WV * 16 + kq * 4) * 2;
+                // ONE atomic instruction per wave and tile: after the row reductions every lane of a 16-lane row holds the row's four (sum, sum of
+                // squares) pairs; lane m < 8 of each row adds component m & 1 of accumulator row m >> 1, so the 32 values of the wave's 16
+                // channels go out as 32 lanes of one global_atomic_add_f64 (eight instructions of 4 lanes each cost 0.2 ms of a 2 ms launch:
+                // a CU retires about one atomic wave-instruction per 50 ns whatever its lane count)
+                float sel[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
-                    if (m == 0) {
-                        atomicAdd(dst + r * 2, (double)s);
-                        atomicAdd(dst + r * 2 + 1, (double)q);
-                    }
+                    sel[r] = (m & 1) ? q : s;
+                }
+                const int rr = (m >> 1) & 3;
+                const float v = rr == 0 ? sel[0] : rr == 1 ? sel[1] : rr == 2 ? sel[2] : sel[3];
+                if (m < 8) {
+                    double* dst = p.stat_acc + fz * p.stat_fs + ((size_t)(blockIdx.x % NREP) * p.stat_C + co0 + WV * 16 + kq * 4 + rr) * 2 + (m & 1);
+                    const double dv = (double)v;
+                    asm volatile("global_atomic_add_f64 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(dv) : "memory");
                 }
             }
         } else {

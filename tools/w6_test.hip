@@ -14,7 +14,7 @@ using namespace ppc;
 int main(int argc, char** argv)
 {
     const int C = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 32, W = argc > 3 ? atoi(argv[3]) : 32, B = argc > 4 ? atoi(argv[4]) : 2;
-    const int twt = argc > 5 ? atoi(argv[5]) : 4, check = argc > 6 ? atoi(argv[6]) : 1, reps = argc > 7 ? atoi(argv[7]) : 3, dbg = argc > 8 ? atoi(argv[8]) : 0;
+    const int twt = argc > 5 ? atoi(argv[5]) : 4, check = argc > 6 ? atoi(argv[6]) : 1, reps = argc > 7 ? atoi(argv[7]) : 3, dbg = argc > 8 ? atoi(argv[8]) : 0, nostat = argc > 9 ? atoi(argv[9]) : 0, nores = argc > 10 ? atoi(argv[10]) : 0;
     const int Cout = C;
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
@@ -45,7 +45,7 @@ int main(int argc, char** argv)
     p.dbg_buf = dbgb;
     p.in = dx; p.w = dw; p.out = dy; p.res = dres; p.Cin = C; p.Hin = H; p.Win = W; p.Cout = Cout; p.Hout = H; p.Wout = W;
     p.pre = PRE_AFFINE; p.pre_scale = dsc; p.pre_shift = dsh; p.aff_fs = 0; p.stat_acc = dst; p.stat_C = C; p.stat_fs = stat_fs;
-    p.dbg = dbg; p.in_fs = fs; p.out_fs = fs; p.res_fs = fs; p.nb = B;
+    p.dbg = dbg; if (nostat) p.stat_acc = nullptr; if (nores) p.res = nullptr; p.in_fs = fs; p.out_fs = fs; p.res_fs = fs; p.nb = B;
     Variant v = twt == 4 ? make_wino6<4>(false) : twt == 1 ? make_wino6<1>(false) : make_wino6<16>(false);
     p.rx0 = 0; p.ry0 = 0; p.rx1 = W; p.ry1 = H; p.rnbx = (W + v.pw - 1) / v.pw; p.rnby = (H + v.ph - 1) / v.ph;
     const int total = p.rnbx * p.rnby * (Cout / 64) * B;
@@ -61,7 +61,7 @@ int main(int argc, char** argv)
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double exec = 2.0 * plane * C * Cout * 2.25 * B;
-    printf("diag %d dbg %d %s C=%d %dx%d B=%d grid=%d: %.3f ms/launch, executed %.1f TFLOP/s (%.3f of 157.3), algorithmic %.1f\n", PP_W6_DIAG, dbg, v.name, C, H, W, B, g, ms, exec / ms * 1e-9,
+    printf("nostat %d nores %d diag %d dbg %d %s C=%d %dx%d B=%d grid=%d: %.3f ms/launch, executed %.1f TFLOP/s (%.3f of 157.3), algorithmic %.1f\n", nostat, nores, PP_W6_DIAG, dbg, v.name, C, H, W, B, g, ms, exec / ms * 1e-9,
            exec / ms * 1e-9 / 157.3, exec * 4 / ms * 1e-9);
 #if PP_W6_DIAG & 512
     {
