@@ -4,7 +4,7 @@ pass each, per forced tiling).
 usage: hbm_traffic.py <out.json> <frames> <algorithmic_bytes> <tiling>=<dir_fetch>,<dir_write> [...]
 
 The roofline layer (3x3 s1 64->64 at 400x400) runs its own copy of the Winograd kernel (symbol
-`wino_mfma<..., 1>`), so its launches are the rows of that symbol.  Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950
+`wino_mfma<..., 1>` / `wino4_mfma<..., 1>` / `wino6_mfma<4, 1>`), so its launches are the rows of that symbol.  Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM): the counters are in KiB; on gfx950
 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so the corrected figure doubles it (both
 are written; the kernel reads dwords, for which the guide calls the absolute uncalibrated, so the true read
 side lies between the two).
@@ -14,9 +14,9 @@ import os, csv, glob, json, re, sys
 
 def rows(d, counter):
     f = max(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
-    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and re.search(r'wino4?_mfma<[^>]*, 1>', r['Kernel_Name'])]
+    rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and re.search(r'wino[46]?_mfma<[^>]*, 1>', r['Kernel_Name'])]
     if not rs:
-        raise SystemExit(f'no {counter} rows for the roofline copy wino(4)_mfma<..., 1> in {f}')
+        raise SystemExit(f'no {counter} rows for the roofline copy wino(4|6)_mfma<..., 1> in {f}')
     vals = [float(r['Counter_Value']) for r in rs]
     return sum(vals) / len(vals), len(vals), rs[0]['Kernel_Name'].replace('(anonymous namespace)::', '')
 
