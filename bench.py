@@ -408,9 +408,10 @@ def main():
                                "frac": round(ach * ratio / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                                "algorithmic_flops_per_launch": k_flops, "executed_flops_per_launch": k_flops * ratio,
-                               "algorithmic_tflops": round(ach, 3),
-                               "note": "achieved / frac price the MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3): 4/9 of the direct-convolution "
-                                       "count in `algorithmic_*`; F(4x4,3x3): 1/4)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
+                               "algorithmic_tflops": round(ach, 3), "algorithmic_frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                               "note": "achieved / frac price the MFMA flops the kernel EXECUTES (hardware utilisation, <= 1): Winograd F(2x2,3x3) executes 4/9 of the "
+                                       "direct-convolution count, F(4x4,3x3) 1/4 -- a FASTER kernel with fewer executed flops shows a LOWER frac; "
+                                       "`algorithmic_tflops` / `algorithmic_frac` price SURVEY 8(d)'s direct-convolution flops against the same peak (> 1 for Winograd)" if ratio < 1.0 else "direct convolution: executed = algorithmic flops"}
         else:
             # 16-bit operands: the same layer is no longer bound by the matrix pipe.  Both floors are stated, the binding one
             # (the larger time) is the roofline: HBM with SURVEY 8(d)'s algorithmic bytes (input read once + output written
