@@ -3328,6 +3328,11 @@ int autotune_layer(pp_ctx* ctx, Layer& L, int Hin, int Win, int Hout, int Wout, 
     snprintf(sig, sizeof(sig), "v%d m%d k%d s%d u%d c%d r%d %dx%d n%d b%d p%d", pp_version(), (int)menu.size(), L.kind, L.stride, L.up, L.cin, L.cout, Hout, Wout,
              ctx->cfg.norm_kind, ctx->max_batch < TUNE_FRAMES ? ctx->max_batch : TUNE_FRAMES, eprec);
     const int rows = (L.kind == 2) ? head_rows(ctx->cfg.num_anchor_per_loc) : (L.kind == 1 ? L.cout * L.up * L.up : L.cout);
+    if (const char* ff = getenv("PP_FORCE_FIRST")) { // experiments: pin the tiling of the first (sparse, stride-2) convolution alone
+        if (first_conv)
+            for (const Variant& v : menu)
+                if (variant_ok(v, rows) && shape_ok(v, Hin, Win, Wout) && strstr(v.name, ff)) { L.var = v; return 0; }
+    }
     if (const char* force = getenv("PP_FORCE_VARIANT")) { // tests: pin a tiling family by name substring
         for (const Variant& v : menu)
             if (variant_ok(v, rows) && shape_ok(v, Hin, Win, Wout) && strstr(v.name, force)) { L.var = v; return 0; }
