@@ -3099,10 +3099,10 @@ int launch_conv(pp_ctx* ctx, const Layer& L, const float* in, int Hin, int Win, 
         p.pmap_fs = (size_t)Hin * Win;
         p.feat_fs = (size_t)ctx->cfg.max_voxels * 64;
     }
-    // one frame per launch: the kernels that can finalise the producer's statistics in their prologue (conv_mfma, wino_res, gemm1x1, wino4_mfma)
+    // one frame per launch: the kernels that can finalise the producer's statistics in their prologue (conv_mfma, wino_res, gemm1x1, wino4_mfma, wino6_mfma)
     // do so, instead of a norm_finalize launch in front of the layer -- 14 launches of 4.7 us + a boundary each per frame at batch 1.
     // (Batched launches keep norm_finalize: a persistent workgroup would redo the fp64 finalisation at every frame change.)
-    const bool fin_in_kernel = B == 1 && (L.var.wino == 0 || L.var.wino == 2 || L.var.wino == 3 || L.var.wino == 4) && !getenv_flag_off("PP_FIN_IN_KERNEL");
+    const bool fin_in_kernel = B == 1 && (L.var.wino == 0 || L.var.wino == 2 || L.var.wino == 3 || L.var.wino == 4 || L.var.wino == 6) && !getenv_flag_off("PP_FIN_IN_KERNEL");
     if (pre.mode == PRE_STATS && net->aff && L.cin <= 320 && !fin_in_kernel) {
         hipLaunchKernelGGL(norm_finalize, dim3(B), dim3(320), 0, stream, pre.acc, pre.fs, L.cin, pre.inv_n, p.eps, net->aff, (size_t)640);
         p.pre = PRE_AFFINE; p.pre_scale = net->aff; p.pre_shift = net->aff + 320; p.aff_fs = 640;

@@ -37,7 +37,7 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef PP_W6_DIAG
-#define PP_W6_DIAG 0 // timing-only ablations (wrong results): 1 no input transform, 2 no raw LDS reads, 4 no A loads, 8 no MFMA, 16 no staging, 32 no epilogue exchange, 64 load side frozen (patch loads hit L2), 128 A loads always the same 72 KB
+#define PP_W6_DIAG 0 // timing-only ablations (wrong results): 1 no input transform, 2 no raw LDS reads, 4 no A loads, 8 no MFMA, 16 no staging, 32 no epilogue exchange, 64 load side frozen (patch loads hit L2), 128 A loads always the same 72 KB, 2048 every A load lands in the VGPR buffer (is the AGPR destination what costs?), 4096 A loads of 4 bytes per lane (requests or bytes?)
 #endif
 
 template <int TWT>
@@ -55,10 +55,15 @@ struct Wino6Cfg {
     }
     static constexpr int RS = rs();
     static constexpr int NQ = RS / 4; // dwordx4 pieces per patch row
+    // TWT = 1 (the 4-pixel column strips: 16 tiles stacked): a row stride that is a multiple of 4 floats puts the 16 tiles' rows on
+    // at most 4 bank quads (8-way conflicts with RS = 8: 30x the conflict cycles of the other families, profiles/r04_pmc_wino.txt).
+    // Patch row r therefore starts at r RS + SK (r / 4): tile ty's rows begin at quad 9 ty + ... -- 16 distinct quads.
+    static constexpr int SK = TWT == 1 ? 4 : 0;
+    static constexpr int row_at(int r) { return r * RS + SK * (r / 4); }
     static constexpr int cs()         // channel stride: a multiple of 64 floats (the kq halves of a read group stay apart)
     {
-        int v = IH * RS;
-        while (v % 64) ++v;
+        int v = row_at(IH - 1) + RS;
+        while (v % (TWT == 1 ? 32 : 64)) ++v; // (the skewed strip patch at a multiple of 64 would not fit the 160 KB next to the exchange buffer)
         return v;
     }
     static constexpr int CS = cs();
@@ -206,12 +211,37 @@ __device__ __forceinline__ void w6_mfma4(const float b, const f32x4& a3)
                         "i"(c0), "i"(c0 + 3), "i"(c0 + 4), "i"(c0 + 7), "i"(c0 + 8), "i"(c0 + 11), "i"(c0 + 12), "i"(c0 + 15) : W6_AGPRS);
     }
 }
+// the same four MFMAs of an AGPR buffer (KB < 3) with the NEXT request for that buffer's quad behind them in ONE statement: the request reads
+// its SGPR operands at least five wait states (four MFMAs + s_nop 1) after anything hipcc may have put in front of the statement (a spill-lane
+// reload, see W6_SGPR_PAD), so it needs no s_nop 4 of its own -- which costs a lone wave 12 cycles per request (tools/vmem_probe.hip: 1180 ->
+// 1292 cycles per k-step of nine requests), 4 % of a chunk
+template <int J, int KB, bool ZERO>
+__device__ __forceinline__ void w6_mfma4_load(const float b, const i32x4 rw, const unsigned voff, const unsigned soff)
+{
+    static_assert(KB < 3, "buffer 3 lives in VGPRs");
+    constexpr int c0 = J * 16, a0 = 144 + (KB * 9 + J) * 4;
+    if constexpr (ZERO)
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%c1:%c2], a[%c9], %0, 0\n\tv_mfma_f32_16x16x4_f32 a[%c3:%c4], a[%c10], %0, 0\n\t"
+                     "v_mfma_f32_16x16x4_f32 a[%c5:%c6], a[%c11], %0, 0\n\tv_mfma_f32_16x16x4_f32 a[%c7:%c8], a[%c12], %0, 0\n\t"
+                     "s_nop 1\n\tbuffer_load_dwordx4 a[%c9:%c12], %13, %14, %15 offen" W6_SYNC
+                     :: "v"(b), "i"(c0), "i"(c0 + 3), "i"(c0 + 4), "i"(c0 + 7), "i"(c0 + 8), "i"(c0 + 11), "i"(c0 + 12), "i"(c0 + 15),
+                        "i"(a0), "i"(a0 + 1), "i"(a0 + 2), "i"(a0 + 3), "v"(voff), "s"(rw), "s"(soff) : W6_AGPRS);
+    else
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%c1:%c2], a[%c9], %0, a[%c1:%c2]\n\tv_mfma_f32_16x16x4_f32 a[%c3:%c4], a[%c10], %0, a[%c3:%c4]\n\t"
+                     "v_mfma_f32_16x16x4_f32 a[%c5:%c6], a[%c11], %0, a[%c5:%c6]\n\tv_mfma_f32_16x16x4_f32 a[%c7:%c8], a[%c12], %0, a[%c7:%c8]\n\t"
+                     "s_nop 1\n\tbuffer_load_dwordx4 a[%c9:%c12], %13, %14, %15 offen" W6_SYNC
+                     :: "v"(b), "i"(c0), "i"(c0 + 3), "i"(c0 + 4), "i"(c0 + 7), "i"(c0 + 8), "i"(c0 + 11), "i"(c0 + 12), "i"(c0 + 15),
+                        "i"(a0), "i"(a0 + 1), "i"(a0 + 2), "i"(a0 + 3), "v"(voff), "s"(rw), "s"(soff) : W6_AGPRS);
+}
 // request the A operands (4 M-tiles: 16 bytes per lane) of (buffer KB, position J): voff = the lane's byte offset, soff = the (k-step, position)'s
 template <int J, int KB>
 __device__ __forceinline__ void w6_load_A(const i32x4 rw, const unsigned voff, const unsigned soff, f32x4& a3)
 {
     if constexpr (PP_W6_DIAG & 4) return;
-    if constexpr (KB < 3) {
+    if constexpr (PP_W6_DIAG & 4096) { // 4 bytes per lane instead of 16: the same requests with a quarter of the data
+        constexpr int a0 = 144 + ((KB < 3 ? KB : 0) * 9 + J) * 4;
+        asm volatile(W6_SGPR_PAD "buffer_load_dword a[%c3], %0, %1, %2 offen" :: "v"(voff), "s"(rw), "s"(soff), "i"(a0) : W6_AGPRS);
+    } else if constexpr (KB < 3 && !(PP_W6_DIAG & 2048)) {
         constexpr int a0 = 144 + (KB * 9 + J) * 4;
         asm volatile(W6_SGPR_PAD "buffer_load_dwordx4 a[%c3:%c4], %0, %1, %2 offen" W6_SYNC :: "v"(voff), "s"(rw), "s"(soff), "i"(a0), "i"(a0 + 3) : W6_AGPRS);
     } else {
@@ -294,7 +324,10 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
     const i32x4 rw = w6_rsrc(p.w, 0x7FFFFFFFu);
     f32x4 xv[2][PRND];
 #pragma unroll
-    for (int rd = 0; rd < PRND; ++rd) loff[rd] = chl * C::CS + 4 * min(l32 + 32 * rd, C::NPC - 1); // RS = 4 NQ: piece e sits at float 4 e
+    for (int rd = 0; rd < PRND; ++rd) { // RS = 4 NQ: piece e sits at float 4 e (+ the skew of its row)
+        const int e = min(l32 + 32 * rd, C::NPC - 1);
+        loff[rd] = chl * C::CS + 4 * e + C::SK * ((e / C::NQ) / 4);
+    }
     int s_lin = lin0, s_ch = 0, s_frame = 0, s_tab = 0;
     int r_c0[2] = {0, 0}, r_tab[2] = {0, 0}, r_lin[2] = {lin0, lin0}, mk_lin = -1; // the chunk held by register set 0 / 1
     unsigned r_vmask[2] = {0u, 0u};
@@ -353,7 +386,7 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
 
     // ---------------- compute side ----------------
     const int tx = m % TWT, ty = m / TWT;
-    const int rbase = kq * C::CS + (4 * ty) * C::RS + 4 * tx;
+    const int rbase = kq * C::CS + (4 * ty) * C::RS + C::SK * ty + 4 * tx;
     constexpr int A0 = (WV == 0) ? 0 : 1, A1 = (WV == 3) ? 5 : 4; // raw patch rows this wave's two rows of B^T d need
     const unsigned wlane = (unsigned)lane * 16u;
     const f32x2 two = {2.f, 2.f};
@@ -367,9 +400,10 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
             pp_steps<decltype(R0)::value, decltype(R1)::value>([&](auto AA) {
                 constexpr int a = decltype(AA)::value;
                 if constexpr (a >= A0 && a <= A1) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(base + a * C::RS);
+                    constexpr int ro = a * C::RS + (a >= 4 ? C::SK : 0); // window row a of tile ty = patch row 4 ty + a
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(base + ro);
                     d[a][0] = lo2(q); d[a][1] = hi2(q);
-                    d[a][2] = *reinterpret_cast<const f32x2*>(base + a * C::RS + 4);
+                    d[a][2] = *reinterpret_cast<const f32x2*>(base + ro + 4);
                 }
             });
         }
@@ -410,7 +444,22 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
     // ---------------- pipeline prologue: chunks 0 and 1 into ring slots 0 and 1, chunks 2 and 3 into the two register sets,
     // the A operands of chunks 0 and 1 into the four buffers ----------------
     set_load_tile(lin0);
-    load_aff(s_frame);
+    if (p.pre == PRE_STATS) {
+        // one frame per launch (launch_conv hands the raw statistics over only then): the producer's fp64 sums become (scale, shift) here,
+        // with norm_finalize's formula, instead of a launch of their own in front of the layer.  No frame change follows.
+        const double* pa = p.pre_acc + (size_t)s_frame * p.pre_fs;
+        for (int c = tid; c < Cin; c += C::THREADS) {
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) { sm += pa[((size_t)r * Cin + c) * 2]; sq += pa[((size_t)r * Cin + c) * 2 + 1]; }
+            const double mean = sm * p.pre_inv_n;
+            double var = sq * p.pre_inv_n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)p.eps);
+            aff[s_tab * 320 + c] = (f32x2){(float)rstd, (float)(-mean * rstd)};
+        }
+    } else
+        load_aff(s_frame);
     __syncthreads();
     {
         pp_steps<0, PRND>([&](auto E) { W6_LOAD_PIECE(0, decltype(E)::value) });
@@ -527,10 +576,15 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
                     // fewer younger operations.  Every wait of an odd chunk's second k-step allows for the (up to) nine missing requests.
                     constexpr int NW = (kb == 3) ? (POS == 1 ? (8 - j) + C::T + C::idx_A(1, j) : C::N_A - 9) : C::N_A;
                     if constexpr (kb == 3) w6_wait<NW>(A3[j]); else w6_wait<NW>();
-                    w6_mfma4<j, kb, first_ && ks == 0>(B[ks][j], A3[j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (kb == 3) { if (ch != nchunk - 1) w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]); }
-                    else w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]);
+                    if constexpr (kb < 3 && !(PP_W6_DIAG & (4 | 8 | 2048 | 4096))) {
+                        w6_mfma4_load<j, kb, first_ && ks == 0>(B[ks][j], rw, wlane, w_off(wnext, ks, j)); // the MFMAs and the buffer's next request
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        w6_mfma4<j, kb, first_ && ks == 0>(B[ks][j], A3[j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (kb == 3) { if (ch != nchunk - 1) w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]); }
+                        else w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]);
+                    }
                     // gaps: raw window rows of the next k-step behind positions 0..2, the two VALU clusters behind 4 and 6
                     if constexpr (j == 0) read_raw(rawn, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
                     if constexpr (j == 1) read_raw(rawn, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
