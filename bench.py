@@ -265,7 +265,7 @@ def main():
         scaling = "weak"
     NB = len(mine)
     frames_per_step = args.global_batch if args.global_batch > 0 else world * NB
-    MAXB = 32  # frames per pp_infer_batch pass; a rank with more frames per step runs several passes
+    MAXB = int(os.environ.get("PP_BENCH_MAXB", "32"))  # frames per pp_infer_batch pass; a rank with more frames per step runs several passes
     passes = [mine[i:i + MAXB] for i in range(0, NB, MAXB)] if NB else []
     # every rank builds its engine for the SAME max_batch -- the busiest rank's frame count (a global batch the world size does
     # not divide gives the ranks different counts): the tuner's key and the Winograd strip decision carry it, so rank 0's
