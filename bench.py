@@ -265,7 +265,7 @@ def main():
         scaling = "weak"
     NB = len(mine)
     frames_per_step = args.global_batch if args.global_batch > 0 else world * NB
-    MAXB = int(os.environ.get("PP_BENCH_MAXB", "32"))  # frames per pp_infer_batch pass; a rank with more frames per step runs several passes
+    MAXB = 64 if (args.batch > 32 and args.global_batch == 0) else 32  # frames per pp_infer_batch pass (pp_create takes up to 64: --batch 64 measured 1002 against 986 frames/s, at twice the memory and latency); a rank with more frames per step runs several passes
     passes = [mine[i:i + MAXB] for i in range(0, NB, MAXB)] if NB else []
     # every rank builds its engine for the SAME max_batch -- the busiest rank's frame count (a global batch the world size does
     # not divide gives the ranks different counts): the tuner's key and the Winograd strip decision carry it, so rank 0's

@@ -14,4 +14,6 @@ cp $O/b1_prof.log $P/r04_batch1_kernel_summary.txt
 cp $O/cfg_nuscene.json $P/r04_bench_config_nuscene.json
 cp $O/cfg_ntusl_10cm.json $P/r04_bench_config_ntusl_10cm.json
 cp $O/cfg_nuscene_10class.json $P/r04_bench_config_nuscene_10class.json
+
+cp $O/batch64.json $P/r04_bench_batch64.json
 ls -la $P | grep r04

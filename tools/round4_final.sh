@@ -21,4 +21,6 @@ timeout -k 10 200 bash tools/b1_prof.sh r04/b1 > $O/b1_prof.log 2>&1 || true
 timeout -k 10 200 python bench.py --config nuscene --no-cpu-baseline --no-extras > $O/cfg_nuscene.json 2> $O/cfg_nuscene.err
 timeout -k 10 300 python bench.py --config ntusl_10cm --batch 16 --no-cpu-baseline --no-extras > $O/cfg_ntusl_10cm.json 2> $O/cfg_ntusl_10cm.err
 timeout -k 10 200 python bench.py --config nuscene_10class --no-cpu-baseline --no-extras > $O/cfg_nuscene_10class.json 2> $O/cfg_nuscene_10class.err
+timeout -k 10 300 python bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/batch64.json 2> $O/batch64.err
+echo "64 frames per pass: $(python tools/print_bench.py $O/batch64.json | head -1)"
 for f in cfg_nuscene cfg_nuscene_10class cfg_ntusl_10cm; do echo "$f: $(python tools/print_bench.py $O/$f.json | head -1)"; done
