@@ -27,17 +27,28 @@ __device__ __forceinline__ void scan_rows_body(int32_t* __restrict__ occ, int gx
     if (row >= gx) return;
     int32_t* r = occ + (size_t)row * gy;
     int carry = 0;
-    for (int y0 = 0; y0 < gy; y0 += 64) {
-        int y = y0 + lane;
-        int v = y < gy ? r[y] : 0;
+    constexpr int NB = 8; // 64-cell pieces requested together: the carry chain then runs on registers, not through one memory round trip per piece
+    for (int yb = 0; yb < gy; yb += 64 * NB) {
+        int vv[NB];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(v, o);
-            if (lane >= o) v += t;
+        for (int b = 0; b < NB; ++b) {
+            const int y = yb + b * 64 + lane;
+            const int x = r[y < gy ? y : gy - 1];
+            vv[b] = y < gy ? x : 0;
         }
-        v += carry;
-        if (y < gy) r[y] = v;
-        carry = __shfl(v, 63);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int y = yb + b * 64 + lane;
+            int v = vv[b];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int t = __shfl_up(v, o);
+                if (lane >= o) v += t;
+            }
+            v += carry;
+            if (y < gy) r[y] = v;
+            carry = __shfl(v, 63);
+        }
     }
 }
 
@@ -48,17 +59,33 @@ __device__ __forceinline__ void scan_cols_body(int32_t* __restrict__ occ, int gx
     int col = blockIdx.x * 64 + lane;
     int rows_per = (gx + 15) / 16;
     int x0 = w * rows_per, x1 = min(gx, x0 + rows_per);
+    // both passes in batches of CH rows requested together (clamped addresses, selects): row by row the segment was a chain of
+    // ~2 x 50 memory round trips on the 13 workgroups a 800-cell grid gives this kernel (23 us of a one-frame call)
+    constexpr int CH = 16;
     int s = 0;
     if (col < gy)
-        for (int x = x0; x < x1; ++x) s += occ[(size_t)x * gy + col];
+        for (int x = x0; x < x1; x += CH) {
+            int v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = occ[(size_t)min(x + i, x1 - 1) * gy + col];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) s += (x + i < x1) ? v[i] : 0;
+        }
     part[w][lane] = s;
     __syncthreads();
     int run = 0;
     for (int k = 0; k < w; ++k) run += part[k][lane];
     if (col < gy)
-        for (int x = x0; x < x1; ++x) {
-            run += occ[(size_t)x * gy + col];
-            occ[(size_t)x * gy + col] = run;
+        for (int x = x0; x < x1; x += CH) {
+            int v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = occ[(size_t)min(x + i, x1 - 1) * gy + col];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (x + i < x1) {
+                    run += v[i];
+                    occ[(size_t)(x + i) * gy + col] = run;
+                }
         }
 }
 

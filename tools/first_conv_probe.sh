@@ -1,4 +1,4 @@
-# PP_FORCE_FIRST sweep: frame time of the 32-frame pass with the first (sparse, stride-2) convolution pinned to each tiling (run on the GPU box)
+# PP_FORCE_FIRST sweep: frame time of the 32-frame pass (or, PP_PROBE_B=1, of one-frame calls) with the first (sparse, stride-2) convolution pinned to each tiling (run on the GPU box)
 for v in "" "k3s2 tw16 w1x4 t4x5 bx1 kc4" "k3s2 tw16 w1x4 t4x4 bx1 kc8" "k3s2 tw16 w2x2 t2x5 bx1 kc4" "k3s2 tw16 w1x4 t2x5 bx1 kc8" "k3s2 tw8 w1x4 t4x4 bx2 kc8" "k3s2 tw4 w2x2 t2x2 bx2 kc8"; do
   export PP_FORCE_FIRST="$v"; [ -z "$v" ] && unset PP_FORCE_FIRST
   python - <<'PY'
@@ -6,12 +6,16 @@ import importlib, os, sys, torch
 sys.path.insert(0, os.getcwd())
 synth=importlib.import_module("3d_object_detection_amd.synth"); eng_mod=importlib.import_module("3d_object_detection_amd.engine")
 cfg=synth.load_config("eight_20cm"); cfg["device"]=torch.device("cuda:0")
-eng=eng_mod.Engine(dict(cfg), max_batch=32); eng.load_state_dict(synth.seeded_state_dict(0))
+B=int(os.environ.get("PP_PROBE_B","32")); eng=eng_mod.Engine(dict(cfg), max_batch=B); eng.load_state_dict(synth.seeded_state_dict(0))
 clouds=[torch.from_numpy(synth.lidar_cloud("eight_20cm", seed=1000+i)).cuda() for i in range(32)]
-eng.infer_batch(clouds); torch.cuda.synchronize()
+def run():
+    if B==1:
+        for c in clouds: eng.infer_frame(c)
+    else: eng.infer_batch(clouds)
+run(); torch.cuda.synchronize()
 e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(5): eng.infer_batch(clouds)
+for _ in range(5): run()
 e1.record(); torch.cuda.synchronize()
 print(os.environ.get("PP_FORCE_FIRST","(tuner)"), "->", eng.layer_tilings()[0]["tiling"], "frame us", round(e0.elapsed_time(e1)/5/32*1e3,1))
 PY
