@@ -16,8 +16,8 @@
 //   tiles (one 16x16-pixel patch, 18x18 with halo, staged once per workgroup) and all 64 output channels of the block.
 // * The transformed weights (36 x Cin x 64 floats per block: 4x the 3x3 filter) are PRIVATE to a wave (its 9 positions), so
 //   they never touch LDS: packed on the host as [block][k-step][wave][position][lane][M-tile] they are the A operands of a
-//   k-step as they lie in memory, fetched global -> VGPR by 9 coalesced dwordx4 loads a whole chunk ahead (L2-resident:
-//   590 KB per 64->64 layer).
+//   k-step as they lie in memory, fetched global -> register (three AGPR buffers, one VGPR buffer) by 9 coalesced dwordx4 requests
+//   per k-step, TWO chunks ahead (vmcnt returns in order: they queue behind the HBM patch pieces); L2-resident: 590 KB per 64->64 layer.
 // * LDS holds the input patches only: a 3-deep ring of 8-channel chunks [c][row][RS] (normalised, ReLU'd, zero-padded while
 //   staging: dwordx4 pieces, 32 threads per channel), walked by a load side that runs two chunks ahead of the MFMAs across
 //   tile boundaries, as in wino4_mfma.
