@@ -719,20 +719,33 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
                 Y[2] = __builtin_elementwise_fma(s34, (f32x4){4.f, 4.f, 4.f, 4.f}, s12);
                 Y[3] = __builtin_elementwise_fma(d34, (f32x4){8.f, 8.f, 8.f, 8.f}, d12) + T[5];
                 f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
-                // residual rows of r: younger operations (all from asm, in this order): rows 0, 1 -- the last chunk's T - 9 requests, the 8
-                // requests of rows 2, 3, the stores of the rows before; rows 2, 3 -- the 4 r stores issued so far
-                pp_steps<0, 4>([&](auto Y_) { w6_wait<(r < 2 ? C::T - 9 + 8 + 4 * r : 4 * r)>(rq[r][decltype(Y_)::value]); });
+                // residual rows of r.  vmcnt orders loads among loads and stores among stores, NOT one against the other: a younger store that
+                // completes first lowers the counter, so a count that allows for pending stores proves nothing about an older load (the first
+                // version waited for rows 2, 3 with "the 4 r stores issued so far" and, once in ~1000 frames, added a residual row that had
+                // not landed: tools/perm_probe.py).  Hence NO store is issued before the last residual wait -- the finished rows stay in the
+                // residual's registers and go out together below -- and the counts are the younger LOADS alone: rows 0, 1 -- the last chunk's
+                // T - 9 requests and the 8 requests of rows 2, 3 (a lower bound for all but the youngest quad); rows 2, 3 -- the quads behind
+                pp_steps<0, 4>([&](auto Y_) {
+                    constexpr int y = decltype(Y_)::value;
+                    w6_wait<(r < 2 ? C::T - 9 + 8 : 7 - (4 * (r - 2) + y))>(rq[r][y]);
+                });
 #pragma unroll
                 for (int y = 0; y < 4; ++y) {
                     const f32x4 v = Y[y] + rq[r][y];
-                    if constexpr (!(PP_W6_DIAG & 1024))
-                        asm volatile(W6_SGPR_PAD "buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(lb), "s"(rout), "s"((unsigned)r * plane_ob + (unsigned)y * row_ob) : "memory");
+                    rq[r][y] = v;
                     sv += v;
                     qv = __builtin_elementwise_fma(v, v, qv);
                 }
                 ssum[r] = pix_ok ? (sv[0] + sv[1]) + (sv[2] + sv[3]) : 0.f;
                 ssq[r] = pix_ok ? (qv[0] + qv[1]) + (qv[2] + qv[3]) : 0.f;
             });
+            if constexpr (!(PP_W6_DIAG & 1024)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        asm volatile(W6_SGPR_PAD "buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(rq[r][y]), "v"(lb), "s"(rout), "s"((unsigned)r * plane_ob + (unsigned)y * row_ob) : "memory");
+            }
 #if PP_W6_DIAG & 512
             { unsigned long long e2b_ = 0; W6_STAMP(e2b_) st_epi4 += e2b_ - e2_; }
 #endif

@@ -585,11 +585,26 @@ def test_full_size_batch_properties(fw, synth):
     # permutation equivariance: reversing the frame order reverses the outputs (every frame changes its stage group)
     det_r, cnt_r = eng.infer_batch(clouds[::-1])
     det_r, cnt_r = det_r.cpu().numpy(), cnt_r.cpu().numpy()
+    # (the near-empty frames -- 7 points, 1 point -- are degenerate for InstanceNorm: almost constant channels, so the last bits of a
+    # statistic are amplified; they get 1e-3 of the row's extent, every other frame 1e-5 -- in practice the passes are bit-identical)
+    tol = [1e-3 if (n is not None and 0 < n < 100) else 1e-5 for n in sizes]
     for i in range(NB):
         assert np.array_equal(cnt_r[NB - 1 - i][:4], cnt_b[i][:4]), i
         k = int(cnt_b[i, 0])
-        np.testing.assert_allclose(det_r[NB - 1 - i, :k], det_b[i, :k], rtol=0, atol=1e-5)
-    # the same call again gives the same detections
-    det_2, cnt_2 = eng.infer_batch(clouds)
-    assert np.array_equal(cnt_2.cpu().numpy()[:, :4], cnt_b[:, :4])
-    np.testing.assert_allclose(det_2.cpu().numpy(), det_b, rtol=0, atol=1e-5)
+        _assert_rows_close(det_r[NB - 1 - i, :k], det_b[i, :k], rel=tol[i])
+    # the same call again gives the same detections -- 30 times: a request that is consumed before it has landed corrupts a tile of
+    # one frame once in a few dozen passes (round 4: wino6_mfma's residual rows behind a wait that allowed for pending stores;
+    # tools/perm_probe.py), which a single repeat almost never sees
+    det_b_gpu = torch.from_numpy(det_b).cuda()
+    live = torch.arange(det_b.shape[1], device="cuda")[None, :] < torch.from_numpy(cnt_b[:, 0].astype(np.int64)).cuda()[:, None]
+    worst = 0.0
+    for rep in range(30):
+        det_2, cnt_2 = eng.infer_batch(clouds)
+        assert np.array_equal(cnt_2.cpu().numpy()[:, :4], cnt_b[:, :4]), rep
+        dev = (det_2[:, :, :6] - det_b_gpu[:, :, :6]).abs().amax(dim=2) / det_b_gpu[:, :, :6].abs().amax(dim=2).clamp_min(1.0)   # [frame, row]
+        dev = torch.where(live, dev, torch.zeros_like(dev))   # rows behind a frame's count are not part of its result
+        per_frame = dev.amax(dim=1).cpu().numpy()
+        worst = max(worst, float(per_frame.max()))
+        for i in range(NB):
+            assert per_frame[i] <= tol[i], (rep, i, float(per_frame[i]))
+    print(f"[batch repeatability] 30 repeats of the 34-frame pass: max deviation {worst:.2e} of a row's extent")
