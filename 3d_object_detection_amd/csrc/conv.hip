@@ -2783,7 +2783,7 @@ void layer_menu(int kind, int stride, int up, std::vector<Variant>& menu, int ci
         menu.push_back(make_wino4<4, 2, 8>(roofline_layer));       // 16x16 px
         menu.push_back(make_wino4<8, 1, 8>(roofline_layer));       // 16x16 px, 8x2-tile N-tiles
         menu.push_back(make_wino4<8, 2, 8>(roofline_layer));       // 32x8 px
-        if (cin % 16 == 0) wino6_menu(menu, roofline_layer);       // Winograd F(4x4,3x3), 16x16 px (wino6.hip)
+        if (cin % 32 == 0) wino6_menu(menu, roofline_layer);       // Winograd F(4x4,3x3), 16x16 px (wino6.hip)
         if (cin == 64) menu.push_back(make_wres<64, 2, 1>());   // 128 KB slab: 64 ch x 32 rows
         if (cin == 128) menu.push_back(make_wres<128, 1, 1>()); // 128 KB slab: 128 ch x 16 rows
     }

@@ -37,7 +37,7 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef PP_W6_DIAG
-#define PP_W6_DIAG 0 // timing-only ablations (wrong results): 1 no input transform, 2 no raw LDS reads, 4 no A loads, 8 no MFMA, 16 no staging, 32 no epilogue exchange, 64 load side frozen (patch loads hit L2), 128 A loads always the same 72 KB, 2048 every A load lands in the VGPR buffer (is the AGPR destination what costs?), 4096 A loads of 4 bytes per lane (requests or bytes?)
+#define PP_W6_DIAG 0 // timing-only ablations (wrong results): 1 no input transform, 2 no raw LDS reads, 4 no A loads, 8 no MFMA, 16 no staging, 32 no epilogue exchange, 64 load side frozen (patch loads hit L2), 128 A loads always the same 72 KB, 2048 every A load lands in the VGPR buffer (is the AGPR destination what costs?), 4096 A loads of 4 bytes per lane (requests or bytes?), 16384 no epilogue
 #endif
 
 template <int TWT>
@@ -519,11 +519,20 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
 
         // one chunk = 8 channels = two k-steps; XP = chunk parity = register set of the load side and A-buffer pair (2 XP, 2 XP + 1)
         // POS: 0 = the tile's first chunk, 1 = its second, 2 = any later one
-        auto chunk_body = [&](auto POS_, auto X_, int ch) {
+        // LAST: the tile's last chunk, a COMPILE-TIME property (the last pair of chunks is peeled off the loop below).  From the residual
+        // requests at its top to their use in the epilogue the code is then one straight line: no branch, no loop exit, no merge at which
+        // the register allocator could reconcile two assignments with v_mov copies -- copies of registers whose requests are still in
+        // flight.  (Round 4 had `if (ch == nchunk - 1)` around them and a run-time debug branch around the epilogue; one build moved
+        // the two youngest residual quads to buffer 3's registers and back at the loop exit, and a tile whose residual took longer than
+        // a chunk to arrive added stale data: 1 launch in 3 .. 3000 in tools/w6_test.hip's soak mode.  tools/inflight_check.py lists
+        // every copy out of a register some request of the kernel lands in.)
+        auto chunk_body = [&](auto POS_, auto X_, auto LAST_, int ch) {
             constexpr int POS = decltype(POS_)::value;
             constexpr bool first_ = POS == 0;
             constexpr int X = decltype(X_)::value;
+            constexpr bool LAST = decltype(LAST_)::value;
             static_assert(POS == 2 || POS == X, "a tile starts on an even chunk");
+            static_assert(!LAST || X == 1, "a tile ends on an odd chunk");
 #if PP_W6_DIAG & 512
             unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0, t4_ = 0, tg_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             W6_STAMP(t0_)
@@ -545,15 +554,13 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
             const unsigned soff_x = (unsigned)(s_ch * KC) * plane_b;
             const float* raw1 = il + buf * C::LDS_IN + 4 * C::CS + rbase;  // this chunk's second channel quad
             const float* raw0n = il + nbuf * C::LDS_IN + rbase;            // the next chunk's first channel quad
-            if constexpr (X == 1) {
-                if (ch == nchunk - 1) {
-                    const float* gres = p.res ? p.res + fz * p.res_fs : p.out;
-                    const i32x4 rres = w6_rsrc(gres, p.res ? frame_bytes : 0u);
+            if constexpr (LAST) {
+                const float* gres = p.res ? p.res + fz * p.res_fs : p.out;
+                const i32x4 rres = w6_rsrc(gres, p.res ? frame_bytes : 0u);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) // rows 0, 1 here; rows 2, 3 at the top of the epilogue, into the registers A buffer 3 gives up
+                for (int r = 0; r < 2; ++r) // rows 0, 1 here; rows 2, 3 at the top of the epilogue, into the registers A buffer 3 gives up
 #pragma unroll
-                        for (int y = 0; y < 4; ++y) w6_load_x4(rq[r][y], rres, lb, (unsigned)r * plane_ob + (unsigned)y * row_ob);
-                }
+                    for (int y = 0; y < 4; ++y) w6_load_x4(rq[r][y], rres, lb, (unsigned)r * plane_ob + (unsigned)y * row_ob);
             }
             __builtin_amdgcn_sched_barrier(0);
             W6_STAMP(t1_)
@@ -582,7 +589,7 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
                     } else {
                         w6_mfma4<j, kb, first_ && ks == 0>(B[ks][j], A3[j]);
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (kb == 3) { if (ch != nchunk - 1) w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]); }
+                        if constexpr (kb == 3) { if constexpr (!LAST) w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]); }
                         else w6_load_A<j, kb>(rw, wlane, w_off(wnext, ks, j), A3[j]);
                     }
                     // gaps: raw window rows of the next k-step behind positions 0..2, the two VALU clusters behind 4 and 6
@@ -623,20 +630,25 @@ __device__ __forceinline__ void wino6_body(const ConvP& p, float* smem)
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
         using P2 = std::integral_constant<int, 2>;
-        chunk_body(P0{}, X0{}, 0);
-        chunk_body(P1{}, X1{}, 1);
+        using LN = std::false_type;
+        using LY = std::true_type;
+        // nchunk >= 4 (Cin >= 32, wino6_menu): first pair, the pairs in between, last pair
+        chunk_body(P0{}, X0{}, LN{}, 0);
+        chunk_body(P1{}, X1{}, LN{}, 1);
 #pragma unroll 1
-        for (int ch = 2; ch < nchunk; ch += 2) {
-            chunk_body(P2{}, X0{}, ch);
-            chunk_body(P2{}, X1{}, ch + 1);
+        for (int ch = 2; ch < nchunk - 2; ch += 2) {
+            chunk_body(P2{}, X0{}, LN{}, ch);
+            chunk_body(P2{}, X1{}, LN{}, ch + 1);
         }
+        chunk_body(P2{}, X0{}, LN{}, nchunk - 2);
+        chunk_body(P2{}, X1{}, LY{}, nchunk - 1);
 
         // ---------------- epilogue ----------------
 #if PP_W6_DIAG & 512
         unsigned long long e0_ = 0, e1_ = 0, e2_ = 0, e3_ = 0;
         W6_STAMP(e0_)
 #endif
-        if (!(p.dbg & 4)) {
+        if constexpr (!(PP_W6_DIAG & 16384)) {
             // an 8-pass MFMA's D needs 12 wait states before anything but the next accumulating MFMA touches it (hipcc pads nothing
             // behind an asm statement)
             asm volatile("s_nop 11" ::: W6_AGPRS);

@@ -7,9 +7,21 @@
 #include <vector>
 #include <cmath>
 #include <random>
+#include <algorithm>
+#include <cstring>
 #include "../3d_object_detection_amd/csrc/wino6.hip"
 using namespace ppc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+// soak mode: compare an output tensor with the first launch's, bit for bit, on the device
+__global__ void soak_cmp(const unsigned* __restrict__ a, const unsigned* __restrict__ ref, size_t n, unsigned long long* __restrict__ res)
+{
+    unsigned cnt = 0;
+    unsigned long long first = ~0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (a[i] != ref[i]) { ++cnt; if (i < first) first = i; }
+    if (cnt) { atomicAdd(res, (unsigned long long)cnt); atomicMin(res + 1, first); }
+}
 
 int main(int argc, char** argv)
 {
@@ -76,6 +88,45 @@ int main(int argc, char** argv)
         }
     }
 #endif
+    if (const char* sk = getenv("W6_SOAK")) { // W6_SOAK=<launches>: repeat the launch and compare output + statistics with the first one's
+        const int n_soak = atoi(sk);
+        float* dref; double* sref; unsigned long long* dres;
+        CK(hipMalloc(&dref, B * fs * 4)); CK(hipMalloc(&sref, B * stat_fs * 8)); CK(hipMalloc(&dres, 32));
+        CK(hipMemset(dst, 0, B * stat_fs * 8));
+        hipLaunchKernelGGL(v.kern, dim3(g), dim3(256), v.lds, 0, p);
+        CK(hipMemcpy(dref, dy, B * fs * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(sref, dst, B * stat_fs * 8, hipMemcpyDeviceToDevice));
+        int bad_launches = 0;
+        for (int it = 0; it < n_soak; ++it) {
+            CK(hipMemsetAsync(dst, 0, B * stat_fs * 8, 0));
+            CK(hipMemsetAsync(dy, 0xff, B * fs * 4, 0));
+            unsigned long long init[4] = {0ull, ~0ull, 0ull, ~0ull};
+            CK(hipMemcpyAsync(dres, init, 32, hipMemcpyHostToDevice, 0));
+            hipLaunchKernelGGL(v.kern, dim3(g), dim3(256), v.lds, 0, p);
+            hipLaunchKernelGGL(soak_cmp, dim3(1024), dim3(256), 0, 0, (const unsigned*)dy, (const unsigned*)dref, B * fs, dres);
+            unsigned long long h[4];
+            CK(hipMemcpy(h, dres, 32, hipMemcpyDeviceToHost));
+            if (h[0]) {
+                ++bad_launches;
+                const size_t i = (size_t)h[1];
+                const size_t fr = i / fs, c = (i % fs) / plane, yy = (i % plane) / W, xx = i % W;
+                printf("soak launch %d: %llu output words differ; first at frame %zu channel %zu y %zu x %zu (tile %zu,%zu; wave/M-tile %zu)\n", it, h[0], fr, c, yy, xx, yy / v.ph, xx / v.pw, (c % 64) / 16);
+                if (bad_launches <= 3) { // the extent of the damage: per-channel and per-row mismatch counts of the first bad frame
+                    std::vector<float> a(fs), r(fs);
+                    CK(hipMemcpy(a.data(), dy + fr * fs, fs * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), dref + fr * fs, fs * 4, hipMemcpyDeviceToHost));
+                    int x0 = W, x1 = -1, y0 = H, y1 = -1, c0 = C, c1 = -1; size_t nb = 0; double mx = 0;
+                    for (size_t q = 0; q < fs; ++q) if (memcmp(&a[q], &r[q], 4)) {
+                        const int cc = (int)(q / plane), y2 = (int)((q % plane) / W), x2 = (int)(q % W);
+                        x0 = std::min(x0, x2); x1 = std::max(x1, x2); y0 = std::min(y0, y2); y1 = std::max(y1, y2); c0 = std::min(c0, cc); c1 = std::max(c1, cc); ++nb;
+                        mx = std::max(mx, (double)fabsf(a[q] - r[q]));
+                    }
+                    printf("   frame %zu: %zu words, channels %d..%d, rows %d..%d, columns %d..%d, max |diff| %.4g\n", fr, nb, c0, c1, y0, y1, x0, x1, mx);
+                    for (int yy2 = y0; yy2 <= std::min(y1, y0 + 7); ++yy2) { printf("   c %d y %d:", c0, yy2); for (int xx2 = x0; xx2 <= std::min(x1, x0 + 7); ++xx2) printf(" %.5g/%.5g", a[(size_t)c0 * plane + yy2 * W + xx2], r[(size_t)c0 * plane + yy2 * W + xx2]); printf("\n"); }
+                }
+            }
+        }
+        printf("soak: %d of %d launches differ from the first\n", bad_launches, n_soak);
+        return bad_launches ? 3 : 0;
+    }
     if (!check) return 0;
     double maxerr = 0; int bad = 0;
     std::vector<int> badmap(plane, 0);
